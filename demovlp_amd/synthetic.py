@@ -1,0 +1,175 @@
+"""Deterministic synthetic inputs and weights for the DemoVLP hot path.
+
+numpy-only (no torch compute, no GPU).  Used by the golden-fixture generator, the tests, ``bench.py``
+and ``__graft_entry__.smoke()`` so that the reference model (in the build container), the CPU oracle and
+the HIP path all see bit-identical inputs and parameters without shipping 600 MB of weights.
+
+Schemas follow what the reference reads:
+  * per-frame region file: keys ``x [Nraw,2048] f32``, ``bbox [Nraw,4] f32``, ``info`` (0-d object array
+    holding ``{objects_conf, objects_id, image_w, image_h}``) -- data_loader/WebVid_dataset.py:243-256
+  * captions: already-tokenised ``input_ids`` / ``attention_mask`` ``[B,100] int64`` -- the trainer pads
+    every caption to ``max_length=100`` (trainer/trainer_dist.py:132-137)
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+FEAT_DIM = 2048
+BOX_DIM = 6
+TEXT_LEN = 100
+VOCAB = 30522
+
+
+# --------------------------------------------------------------------------------------------------
+# region files
+# --------------------------------------------------------------------------------------------------
+def make_frame(sample: int, frame: int, n_raw: int = 36, image_w: int = 640, image_h: int = 360) -> dict:
+    """One synthetic bottom-up-attention frame."""
+    rng = np.random.default_rng(1234 + 64 * sample + frame)
+    x = np.maximum(rng.standard_normal((n_raw, FEAT_DIM), dtype=np.float32), 0.0).astype(np.float32)
+    x0 = (rng.random(n_raw, dtype=np.float32) * np.float32(0.6) * np.float32(image_w)).astype(np.float32)
+    y0 = (rng.random(n_raw, dtype=np.float32) * np.float32(0.6) * np.float32(image_h)).astype(np.float32)
+    bw = ((np.float32(0.05) + rng.random(n_raw, dtype=np.float32) * np.float32(0.35)) * np.float32(image_w)).astype(np.float32)
+    bh = ((np.float32(0.05) + rng.random(n_raw, dtype=np.float32) * np.float32(0.35)) * np.float32(image_h)).astype(np.float32)
+    bbox = np.stack([x0, y0, x0 + bw, y0 + bh], axis=1).astype(np.float32)
+    while True:
+        conf = (np.float32(0.2) + rng.random(n_raw, dtype=np.float32) * np.float32(0.8)).astype(np.float32)
+        if len(np.unique(conf)) == n_raw:  # ties are order-undefined in numpy's argsort -> keep distinct
+            break
+    ids = rng.integers(0, 1600, n_raw).astype(np.int64)
+    return dict(x=x, bbox=bbox, objects_conf=conf, objects_id=ids, image_w=image_w, image_h=image_h)
+
+
+def save_frame_npz(path: str, frame: dict) -> None:
+    """Write a frame in the exact .npz schema the reference loader expects."""
+    info = np.array(dict(objects_conf=frame["objects_conf"], objects_id=frame["objects_id"],
+                         image_w=frame["image_w"], image_h=frame["image_h"]), dtype=object)
+    np.savez(path, x=frame["x"], bbox=frame["bbox"], info=info)
+
+
+def raw_region_batch(batch: int, frames: int, n_raw: int = 36, first_sample: int = 0):
+    """Raw (unselected) region tensors for a batch: feats [B,F,Nraw,2048], bbox [B,F,Nraw,4],
+    conf [B,F,Nraw], image_wh [B,F,2] (all f32)."""
+    feats = np.empty((batch, frames, n_raw, FEAT_DIM), np.float32)
+    bbox = np.empty((batch, frames, n_raw, 4), np.float32)
+    conf = np.empty((batch, frames, n_raw), np.float32)
+    wh = np.empty((batch, frames, 2), np.float32)
+    for b in range(batch):
+        for f in range(frames):
+            fr = make_frame(first_sample + b, f, n_raw)
+            feats[b, f], bbox[b, f], conf[b, f] = fr["x"], fr["bbox"], fr["objects_conf"]
+            wh[b, f] = (fr["image_w"], fr["image_h"])
+    return feats, bbox, conf, wh
+
+
+def fast_region_batch(batch: int, frames: int, regions: int, seed: int = 7, pad_every: int = 5):
+    """Cheap already-selected batch for throughput runs: object [B,F,R,2054] f32, mask [B,F,R] f32.
+    Every ``pad_every``-th frame has 3 padded (masked) regions so the mask path is exercised."""
+    rng = np.random.default_rng(seed)
+    obj = np.maximum(rng.standard_normal((batch, frames, regions, FEAT_DIM + BOX_DIM), dtype=np.float32), 0.0)
+    box = rng.random((batch, frames, regions, BOX_DIM), dtype=np.float32)
+    obj[..., FEAT_DIM:] = box
+    mask = np.ones((batch, frames, regions), np.float32)
+    flat = mask.reshape(-1, regions)
+    flat[::pad_every, regions - 3:] = 0.0
+    return obj.astype(np.float32), mask
+
+
+# --------------------------------------------------------------------------------------------------
+# captions
+# --------------------------------------------------------------------------------------------------
+def caption_batch(batch: int, first_sample: int = 0, text_len: int = TEXT_LEN):
+    """input_ids / attention_mask [B,text_len] int64: [CLS]=101 + random word pieces + [SEP]=102, 0-padded."""
+    ids = np.zeros((batch, text_len), np.int64)
+    att = np.zeros((batch, text_len), np.int64)
+    for b in range(batch):
+        rng = np.random.default_rng(4321 + first_sample + b)
+        n = int(rng.integers(6, 33))
+        body = rng.integers(1000, VOCAB, n - 2)
+        ids[b, 0] = 101
+        ids[b, 1:n - 1] = body
+        ids[b, n - 1] = 102
+        att[b, :n] = 1
+    return ids, att
+
+
+# --------------------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------------------
+def state_dict_schema(num_frames: int, object_num: int) -> "dict[str, tuple]":
+    """Name -> shape of every tensor in ``ObjectRelation.state_dict()`` (280 tensors)."""
+    D, Hd = 768, 3072
+    s: "dict[str, tuple]" = {}
+    s["text_model.embeddings.word_embeddings.weight"] = (VOCAB, D)
+    s["text_model.embeddings.position_embeddings.weight"] = (512, D)
+    s["text_model.embeddings.LayerNorm.weight"] = (D,)
+    s["text_model.embeddings.LayerNorm.bias"] = (D,)
+    for l in range(6):
+        p = f"text_model.transformer.layer.{l}."
+        for n in ("q_lin", "k_lin", "v_lin", "out_lin"):
+            s[p + f"attention.{n}.weight"] = (D, D)
+            s[p + f"attention.{n}.bias"] = (D,)
+        s[p + "sa_layer_norm.weight"] = (D,)
+        s[p + "sa_layer_norm.bias"] = (D,)
+        s[p + "ffn.lin1.weight"] = (Hd, D)
+        s[p + "ffn.lin1.bias"] = (Hd,)
+        s[p + "ffn.lin2.weight"] = (D, Hd)
+        s[p + "ffn.lin2.bias"] = (D,)
+        s[p + "output_layer_norm.weight"] = (D,)
+        s[p + "output_layer_norm.bias"] = (D,)
+    s["object_model.cls_token"] = (1, 1, D)
+    s["object_model.custom_pos_embed"] = (1, object_num + 1, D)
+    s["object_model.temporal_embed"] = (1, num_frames, D)
+    for l in range(12):
+        p = f"object_model.blocks.{l}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (Hd, D)
+        s[p + "mlp.fc1.bias"] = (Hd,)
+        s[p + "mlp.fc2.weight"] = (D, Hd)
+        s[p + "mlp.fc2.bias"] = (D,)
+        s[p + "norm3.weight"] = (D,)
+        s[p + "norm3.bias"] = (D,)
+    s["object_model.norm.weight"] = (D,)
+    s["object_model.norm.bias"] = (D,)
+    s["object_model.object_embedding.weight"] = (D, FEAT_DIM)
+    s["object_model.object_embedding.bias"] = (D,)
+    s["object_model.pos_embedding.weight"] = (D, BOX_DIM)
+    s["object_model.pos_embedding.bias"] = (D,)
+    s["object_model.proj.weight"] = (256, D)
+    s["txt_proj.1.weight"] = (256, D)
+    s["txt_proj.1.bias"] = (256,)
+    return s
+
+
+def fill_tensor(name: str, shape) -> np.ndarray:
+    """Deterministic value of one parameter: a PCG64 stream keyed by crc32(name).
+
+    LayerNorm gains sit around 1, biases are small, matrices use std 0.02 (ViT/BERT init scale) except the
+    two 256-d projection heads which get a larger std so the contrastive logits are not degenerate."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    shape = tuple(shape)
+    z = rng.standard_normal(shape, dtype=np.float32)
+    leaf = name.rsplit(".", 1)[-1]
+    is_norm = ("norm" in name.lower()) and len(shape) == 1
+    if is_norm and leaf == "weight":
+        return (1.0 + 0.1 * z).astype(np.float32)
+    if leaf == "bias":
+        return (0.02 * z).astype(np.float32)
+    if name in ("object_model.proj.weight", "txt_proj.1.weight"):
+        return (0.05 * z).astype(np.float32)
+    if name == "object_model.pos_embedding.weight":
+        return (0.2 * z).astype(np.float32)
+    return (0.02 * z).astype(np.float32)
+
+
+def fill_state_dict(num_frames: int, object_num: int) -> "dict[str, np.ndarray]":
+    return {k: fill_tensor(k, shp) for k, shp in state_dict_schema(num_frames, object_num).items()}

@@ -1,0 +1,115 @@
+"""The CPU oracle (oracle/restatement.py) against golden vectors produced by the unmodified reference
+(tests/golden/make_golden.py).  Runs anywhere; no GPU, no /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from demovlp_amd import synthetic as syn
+from oracle import restatement as orc
+from helpers import load_golden, oracle_clip, golden_batch, rel_err, n_raw_for
+
+TOL = 1e-4   # north_star: within 1e-4 fp32 (relative to max(1, |ref|_inf))
+
+
+@pytest.mark.parametrize("sample", [0, 1, 2, 3])
+@pytest.mark.parametrize("R", [30, 36])
+def test_region_select_bit_exact(sample, R):
+    g = load_golden("g1_region_select.npz")
+    obj, mask, lens, orders = oracle_clip(sample, 3, R)
+    key = f"s{sample}_R{R}"
+    assert list(g[key + "_lens"]) == lens
+    for f in range(3):
+        assert np.array_equal(g[key + "_order"][f, : lens[f]], orders[f])
+    assert np.array_equal(g[key + "_mask"], mask)
+    assert np.array_equal(g[key + "_geo"], obj[..., 2048:])           # f32 divides: bit-exact
+    assert np.array_equal(g[key + "_featsum"], obj[..., :2048].astype(np.float64).sum(-1))
+
+
+@pytest.mark.parametrize("key", ["B2_G288", "B4_G288", "B8_G240", "B3_G30", "B2_G1152"])
+def test_xattn_and_rwa(key):
+    g = load_golden("g4_losses.npz")
+    B = int(key[1:key.index("_")]); G = int(key[key.index("G") + 1:]); W = 99
+    rng = np.random.default_rng(int(g[key + "_seed"][0]))
+    im = rng.standard_normal((B, G, 256), dtype=np.float32)
+    cap = rng.standard_normal((B, W, 256), dtype=np.float32)
+    n = min(G, W)
+    cap[:, :n, :64] += im[:, :n, :64] * 0.5
+    m_img = np.zeros((B, G), np.float32); m_img[1, G - 5:] = -100.0
+    lens = rng.integers(5, 30, B)
+    assert np.array_equal(lens, g[key + "_lens"])
+    m_cap = np.full((B, W), -100.0, np.float32)
+    for b in range(B):
+        m_cap[b, : lens[b]] = 0.0
+    t = lambda a: torch.from_numpy(a)
+    s = orc.xattn_scores(t(im), t(cap), t(m_img), t(m_cap))
+    assert rel_err(s.numpy(), g[key + "_scores"]) < TOL
+    sb = orc.xattn_scores_batched(t(im), t(cap), t(m_img), t(m_cap))
+    assert rel_err(sb.numpy(), g[key + "_scores"]) < TOL
+    s2 = orc.xattn_scores(t(im), t(cap), t(m_img), t(m_cap), gate=False)
+    assert rel_err(s2.numpy(), g[key + "_scores_nogate"]) < TOL
+    assert abs(orc.rwa_loss(s).item() - g[key + "_rwa"][0]) < TOL * max(1, abs(g[key + "_rwa"][0]))
+
+
+def test_sim_matrix_norm_softmax():
+    g = load_golden("g4_losses.npz")
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((16, 256), dtype=np.float32)
+    b = rng.standard_normal((16, 256), dtype=np.float32) + 0.3 * a
+    sm = orc.sim_matrix(torch.from_numpy(a), torch.from_numpy(b))
+    assert rel_err(sm.numpy(), g["ns_sim"]) < 1e-6
+    assert abs(orc.norm_softmax_loss(sm).item() - g["ns_loss"][0]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,with_grads", [("F8_R36_B2", True), ("F8_R30_B3", True), ("F1_R30_B4", True),
+                                            ("F32_R36_B2", False)])
+def test_model_forward_backward(tag, with_grads):
+    g = load_golden(f"g2_model_{tag}.npz")
+    F, R, B = int(g["F"]), int(g["R"]), int(g["B"])
+    obj, mask, ids, att = golden_batch(F, R, B)
+    torch.set_num_threads(8)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=with_grads)
+    obj_t, mask_t = torch.from_numpy(obj), torch.from_numpy(mask).float()
+    ids_t, att_t = torch.from_numpy(ids), torch.from_numpy(att)
+    ttaps, otaps = {}, {}
+    with torch.set_grad_enabled(with_grads):
+        t = orc.text_encoder(p, ids_t, att_t, ttaps)
+        o, add_mask = orc.object_encoder(p, obj_t, mask_t, otaps)
+        out = dict(global_text_embeddings=t[:, 0], local_text_embeddings=t[:, 1:], global_object_embeddings=o[:, 0],
+                   local_object_embeddings=o[:, 1:], object_mask=add_mask[:, 1:])
+        tmask = (att_t[:, 1:].float() - 1.0) * 100.0
+        loss, gl, ll, sim, xs = orc.global_local_loss(out, tmask)
+    for k in ("global_text_embeddings", "local_text_embeddings", "global_object_embeddings", "local_object_embeddings",
+              "object_mask"):
+        assert rel_err(out[k].detach().numpy(), g[k]) < TOL, k
+    for l in (0, 5, 11):
+        assert rel_err(otaps[f"block{l}"].detach().numpy()[:, ::17], g[f"obj_block{l}"]) < TOL, l
+    for l in (0, 5):
+        assert rel_err(ttaps[f"text_layer{l}"].detach().numpy()[:, ::17], g[f"text_layer{l}"]) < TOL, l
+    assert rel_err(sim.detach().numpy(), g["sim_matrix"]) < TOL
+    assert rel_err(xs.detach().numpy(), g["xattn_scores"]) < TOL
+    assert np.allclose([loss.item(), gl.item(), ll.item()], g["losses"], rtol=0, atol=1e-4 * max(1, g["losses"][0]))
+    if not with_grads:
+        return
+    loss.backward()
+    names = list(g["grad_names"])
+    nograd = set(g["nograd_names"])
+    for k, v in p.items():
+        if k in nograd:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+    norms = dict(zip(names, g["grad_norms"]))
+    worst = 0.0
+    for k in names:
+        mine = float(p[k].grad.double().norm())
+        worst = max(worst, abs(mine - norms[k]) / max(norms[k], 1e-4))   # k_lin.bias grads are exactly 0 in theory
+    assert worst < 1e-3, worst      # norms of 254 grad tensors
+    for k in g.files:
+        if k.startswith("grad/"):
+            name = k[5:]
+            ref = g[k]
+            assert np.abs(p[name].grad.numpy() - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-4), name
+        if k.startswith("gradval/"):
+            name = k[8:]
+            idx = g["gradidx/" + name]
+            ref = g[k]
+            got = p[name].grad.numpy().reshape(-1)[idx]
+            assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), name
