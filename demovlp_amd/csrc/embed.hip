@@ -1,0 +1,223 @@
+// Tower prologues: region-feature split/cast + token assembly (A2, model/object_transformer.py:400-433), DistilBERT
+// embedding gather + LayerNorm (A8), dtype casts.  All HBM-bound element-wise work; 8/16-byte accesses where rows allow.
+#include "common.h"
+
+constexpr int FEAT = 2048, BOX = 6, EMB = 768;
+
+// obj [M, 2054] f32 -> feat [M, 2048] T (contiguous, 16-B aligned rows for the embed GEMM) + box [M, 6] f32
+template <typename T>
+__global__ void obj_split_kernel(int64_t M, const float* __restrict__ obj, T* __restrict__ feat, float* __restrict__ box) {
+    const int64_t m = blockIdx.x;
+    const float* src = obj + m * (FEAT + BOX);
+    // rows are only 8-byte aligned (2054 * 4 B): float2 loads
+    for (int i = threadIdx.x; i < FEAT / 2; i += blockDim.x) {
+        const float2 v = *(const float2*)(src + 2 * i);
+        feat[m * FEAT + 2 * i] = from_f<T>(v.x);
+        feat[m * FEAT + 2 * i + 1] = from_f<T>(v.y);
+    }
+    if (threadIdx.x < BOX) box[m * BOX + threadIdx.x] = src[FEAT + threadIdx.x];
+}
+
+// x[b,0,:] = cls + pos0 ; x[b,1+t,:] = tok[b*FR+t,:] + Wp box + bp + temporal[t / R]   (tok already holds W_o feat + b_o)
+// addmask[b,n] = (mask01 - 1) * 100 with CLS = 0
+template <typename T>
+__global__ void embed_assemble_kernel(int B, int F, int R, const T* __restrict__ tok, const float* __restrict__ box,
+                                      const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ temporal,
+                                      const float* __restrict__ cls, const float* __restrict__ pos0, const float* __restrict__ mask01,
+                                      T* __restrict__ x, float* __restrict__ addmask) {
+    const int N = 1 + F * R;
+    const int64_t row = blockIdx.x;                // b*N + n
+    const int b = (int)(row / N), n = (int)(row % N);
+    if (n == 0) {
+        for (int d = threadIdx.x; d < EMB; d += blockDim.x) x[row * EMB + d] = from_f<T>(cls[d] + pos0[d]);
+        if (threadIdx.x == 0) addmask[row] = 0.f;
+        return;
+    }
+    const int64_t m = (int64_t)b * F * R + (n - 1);
+    const int f = (n - 1) / R;
+    float bx[BOX];
+#pragma unroll
+    for (int c = 0; c < BOX; ++c) bx[c] = box[m * BOX + c];
+    for (int d = threadIdx.x; d < EMB; d += blockDim.x) {
+        // the reference adds in this order: (W_o feat + b_o) + (W_p box + b_p), then + temporal  (:404-432)
+        float pe = 0.f;
+#pragma unroll
+        for (int c = 0; c < BOX; ++c) pe += bx[c] * Wp[d * BOX + c];
+        const float v = (to_f(tok[m * EMB + d]) + (pe + bp[d])) + temporal[f * EMB + d];
+        x[row * EMB + d] = from_f<T>(v);
+    }
+    if (threadIdx.x == 0) addmask[row] = (mask01[m] - 1.f) * 100.f;
+}
+
+// dtok[b*FR + t, :] = dx[b, 1+t, :]
+template <typename T>
+__global__ void embed_unassemble_kernel(int B, int F, int R, const T* __restrict__ dx, T* __restrict__ dtok) {
+    const int64_t m = blockIdx.x;
+    const int FR = F * R;
+    const int64_t src = (m / FR) * (FR + 1) + 1 + (m % FR);
+    for (int d = threadIdx.x; d < EMB; d += blockDim.x) dtok[m * EMB + d] = dx[src * EMB + d];
+}
+
+// stage 1 of dWp[d][c] = sum_m dtok[m][d] * box[m][c]: partial[p][c][d]
+template <typename T>
+__global__ void box_wgrad_kernel(int64_t M, const T* __restrict__ dtok, const float* __restrict__ box, int64_t rows_per, float* __restrict__ partial) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= EMB) return;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
+    float acc[BOX];
+#pragma unroll
+    for (int c = 0; c < BOX; ++c) acc[c] = 0.f;
+    for (int64_t m = m0; m < m1; ++m) {
+        const float g = to_f(dtok[m * EMB + d]);
+#pragma unroll
+        for (int c = 0; c < BOX; ++c) acc[c] += g * box[m * BOX + c];
+    }
+#pragma unroll
+    for (int c = 0; c < BOX; ++c) partial[((int64_t)blockIdx.y * BOX + c) * EMB + d] = acc[c];
+}
+__global__ void box_wgrad_reduce_kernel(int64_t P, const float* __restrict__ partial, float* __restrict__ dWp, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // i = c*EMB + d
+    if (i >= BOX * EMB) return;
+    const int c = i / EMB, d = i % EMB;
+    float s = 0.f;
+    for (int64_t p = 0; p < P; ++p) s += partial[p * BOX * EMB + i];
+    dWp[d * BOX + c] = accumulate ? dWp[d * BOX + c] + s : s;
+}
+
+// DistilBERT embeddings: e = word[id] + pos[l] (saved), y = LN(e)
+template <typename T>
+__global__ __launch_bounds__(256) void text_embed_kernel(int64_t M, int L, const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, T* __restrict__ e_out, T* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t id = ids[row];
+    const int l = (int)(row % L);
+    float v[12];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 w = *(const float4*)(word + id * EMB + c * 256 + lane * 4);
+        const float4 p = *(const float4*)(pos + (int64_t)l * EMB + c * 256 + lane * 4);
+        v[4 * c] = w.x + p.x; v[4 * c + 1] = w.y + p.y; v[4 * c + 2] = w.z + p.z; v[4 * c + 3] = w.w + p.w;
+        // the saved pre-LN sum is what LayerNorm backward sees: normalise the value actually stored
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const T t = from_f<T>(v[4 * c + j]); e_out[row * EMB + c * 256 + lane * 4 + j] = t; v[4 * c + j] = to_f(t); s += v[4 * c + j]; }
+    }
+    const float mean = wave_sum(s) / (float)EMB;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { const float d = v[j] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)EMB + eps);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c * 256 + lane * 4 + j;
+            y[row * EMB + col] = from_f<T>((v[4 * c + j] - mean) * rstd * gamma[col] + beta[col]);
+        }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dword[id] += de[row] (padding_idx 0 gets no gradient); float atomics (only [CLS]/[SEP] rows collide)
+template <typename T>
+__global__ void text_embed_bwd_kernel(int64_t M, const int64_t* __restrict__ ids, const T* __restrict__ de, float* __restrict__ dword) {
+    const int64_t row = blockIdx.x;
+    const int64_t id = ids[row];
+    if (id == 0) return;
+    for (int d = threadIdx.x; d < EMB; d += blockDim.x) atomicAdd(dword + id * EMB + d, to_f(de[row * EMB + d]));
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(int64_t n, const S* __restrict__ src, D* __restrict__ dst) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[i + j] = (D)(float)src[i + j];
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = (D)(float)src[j];
+        }
+    }
+}
+
+extern "C" int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* box, void* stream) {
+    if (M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(obj_split_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, M, obj, (float*)feat, box);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(obj_split_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, M, obj, (bf16*)feat, box);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+extern "C" int dvlp_embed_assemble(int dtype, int64_t B, int64_t F, int64_t R, const void* tok, const float* box, const float* Wp,
+                                   const float* bp, const float* temporal, const float* cls, const float* pos0, const float* mask01,
+                                   void* x, float* addmask, void* stream) {
+    if (B <= 0 || F <= 0 || R <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(B * (1 + F * R))), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(embed_assemble_kernel<float>, grid, block, 0, st, (int)B, (int)F, (int)R, (const float*)tok, box, Wp, bp, temporal, cls, pos0, mask01, (float*)x, addmask);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(embed_assemble_kernel<bf16>, grid, block, 0, st, (int)B, (int)F, (int)R, (const bf16*)tok, box, Wp, bp, temporal, cls, pos0, mask01, (bf16*)x, addmask);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+extern "C" int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R, const void* dx, void* dtok, void* stream) {
+    if (B <= 0 || F <= 0 || R <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(B * F * R)), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(embed_unassemble_kernel<float>, grid, block, 0, st, (int)B, (int)F, (int)R, (const float*)dx, (float*)dtok);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(embed_unassemble_kernel<bf16>, grid, block, 0, st, (int)B, (int)F, (int)R, (const bf16*)dx, (bf16*)dtok);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+// workspace: fp32 [dvlp_box_wgrad_chunks(M) * 6 * 768]
+extern "C" int64_t dvlp_box_wgrad_chunks(int64_t M) { const int64_t c = cdiv(M, 64); return c < 256 ? c : 256; }
+extern "C" int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const float* box, float* dWp, float* workspace, int accumulate, void* stream) {
+    if (M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = dvlp_box_wgrad_chunks(M), rows_per = cdiv(M, P);
+    dim3 grid(3, (unsigned)P), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(box_wgrad_kernel<float>, grid, block, 0, st, M, (const float*)dtok, box, rows_per, workspace);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(box_wgrad_kernel<bf16>, grid, block, 0, st, M, (const bf16*)dtok, box, rows_per, workspace);
+    else return DVLP_ERR_DTYPE;
+    hipLaunchKernelGGL(box_wgrad_reduce_kernel, dim3((BOX * EMB + 255) / 256), dim3(256), 0, st, P, workspace, dWp, accumulate);
+    return dvlp_launch_status();
+}
+
+extern "C" int dvlp_text_embed_fwd(int dtype, int64_t B, int64_t L, const int64_t* ids, const float* word, const float* pos,
+                                   const float* gamma, const float* beta, float eps, void* e_out, void* y, float* mean, float* rstd,
+                                   void* stream) {
+    if (B <= 0 || L <= 0 || L > 512) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = B * L;
+    dim3 grid((unsigned)cdiv(M, 4)), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(text_embed_kernel<float>, grid, block, 0, st, M, (int)L, ids, word, pos, gamma, beta, eps, (float*)e_out, (float*)y, mean, rstd);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(text_embed_kernel<bf16>, grid, block, 0, st, M, (int)L, ids, word, pos, gamma, beta, eps, (bf16*)e_out, (bf16*)y, mean, rstd);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+// dword must be zeroed by the caller (dense [V,768] gradient, as nn.Embedding produces)
+extern "C" int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, const void* de, float* dword, void* stream) {
+    if (M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(text_embed_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, M, ids, (const float*)de, dword);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(text_embed_bwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, M, ids, (const bf16*)de, dword);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+extern "C" int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
+    if (n <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = cdiv(n, 1024); if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    if (src_dtype == DVLP_F32 && dst_dtype == DVLP_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, block, 0, st, n, (const float*)src, (bf16*)dst);
+    else if (src_dtype == DVLP_BF16 && dst_dtype == DVLP_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, block, 0, st, n, (const bf16*)src, (float*)dst);
+    else if (src_dtype == DVLP_F32 && dst_dtype == DVLP_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, st, n, (const float*)src, (float*)dst);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}

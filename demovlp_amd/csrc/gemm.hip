@@ -1,0 +1,367 @@
+// GEMM family for the DemoVLP hot path (K3/K5/K6/K7 of SURVEY.md section 2.2 and their backward products).
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// Operand storage ("form"):   form K: element (r,k) at X[r*ld + k]   (k contiguous; nn.Linear weight / activations)
+//                             form R: element (r,k) at X[k*ld + r]   (row index contiguous)
+//   forward  y  = x W^T      : A = x  form K, B = W  form K      (transA=0, transB=0)
+//   backward dx = dy W       : A = dy form K, B = W  form R      (transA=0, transB=1)
+//   backward dW = dy^T x     : A = dy form R, B = x  form R      (transA=1, transB=1)
+//
+// f32 path : v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulate (bitwise an fmaf chain), used for the
+//            1e-4 parity runs.  128x128x16 tile, LDS tiles stored k-major so every operand read is conflict-free.
+// bf16 path: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  128x128x64 tile, 4 waves (2x2), register-prefetched
+//            double-buffered LDS, one barrier per K tile, XCD-aware tile order.  form K operands read fragments with
+//            ds_read_b128 from padded row-major tiles; form R operands are staged k-major and read with the gfx950
+//            transposing LDS read (ds_read_b64_tr_b16), so no activation transposes are materialised in HBM.
+#include "common.h"
+#include <vector>
+
+struct Epi {
+    const float* bias;   // [N] fp32 or null
+    const void* res;     // residual [M, ldres] (same dtype as C) or null
+    void* aux;           // GELU: pre-activation out; *_BWD: pre-activation in
+    int64_t ldres, ldaux;
+    int flags;
+    float alpha;
+    int64_t sA, sB, sC, sRes, sAux;   // batch strides in elements (blockIdx.y = batch index)
+};
+
+template <typename T>
+__device__ __forceinline__ void epi_store(const Epi& e, T* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float v) {
+    v *= e.alpha;
+    if (e.bias) v += e.bias[n];
+    if (e.flags & EPI_GELU) {
+        ((T*)e.aux)[m * e.ldaux + n] = from_f<T>(v);
+        v = gelu_erf(v);
+    }
+    if (e.flags & EPI_LEAKY) v = v > 0.f ? v : 0.1f * v;
+    if (e.flags & EPI_GELU_BWD) v *= gelu_erf_grad(to_f(((const T*)e.aux)[m * e.ldaux + n]));
+    if (e.flags & EPI_RELU_BWD) v = to_f(((const T*)e.aux)[m * e.ldaux + n]) > 0.f ? v : 0.f;
+    if (e.res) v += to_f(((const T*)e.res)[m * e.ldres + n]);
+    if (e.flags & EPI_OUT_F32) {
+        float* Cf = (float*)C;
+        if (e.flags & EPI_ACCUM) v += Cf[m * ldc + n];
+        Cf[m * ldc + n] = v;
+        return;
+    }
+    if (e.flags & EPI_ACCUM) v += to_f(C[m * ldc + n]);
+    C[m * ldc + n] = from_f<T>(v);
+}
+
+// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of tiles
+// (neighbouring tiles share an A panel -> L2 hits).  Bijective for any grid size.
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
+    const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// f32 kernel
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int F_BM = 128, F_BN = 128, F_BK = 16, F_LD = F_BM + 4;
+
+template <bool FORM_R>
+__device__ __forceinline__ void f32_stage(float (*S)[F_LD], const float* __restrict__ X, int64_t ld, int64_t r0, int64_t k0,
+                                          int64_t R, int64_t K, bool vec_ok, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = tid + 256 * i;
+        if (FORM_R) {  // X[k*ld + r]: float4 along r
+            const int k = p >> 5, rq = (p & 31) * 4;
+            const int64_t gk = k0 + k, gr = r0 + rq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K) {
+                const float* src = X + gk * ld + gr;
+                if (vec_ok && gr + 3 < R) v = *(const float4*)src;
+                else {
+                    if (gr + 0 < R) v.x = src[0];
+                    if (gr + 1 < R) v.y = src[1];
+                    if (gr + 2 < R) v.z = src[2];
+                    if (gr + 3 < R) v.w = src[3];
+                }
+            }
+            *(float4*)&S[k][rq] = v;
+        } else {       // X[r*ld + k]: float4 along k
+            const int row = p >> 2, kq = (p & 3) * 4;
+            const int64_t gr = r0 + row, gk = k0 + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < R) {
+                const float* src = X + gr * ld + gk;
+                if (vec_ok && gk + 3 < K) v = *(const float4*)src;
+                else {
+                    if (gk + 0 < K) v.x = src[0];
+                    if (gk + 1 < K) v.y = src[1];
+                    if (gk + 2 < K) v.z = src[2];
+                    if (gk + 3 < K) v.w = src[3];
+                }
+            }
+            S[kq + 0][row] = v.x; S[kq + 1][row] = v.y; S[kq + 2][row] = v.z; S[kq + 3][row] = v.w;
+        }
+    }
+}
+
+template <bool A_R, bool B_R>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+                                                       Epi e, int a_vec, int b_vec, int64_t ntn) {
+    __shared__ __attribute__((aligned(16))) float As[F_BK][F_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[F_BK][F_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (wg / ntn) * F_BM, n0 = (wg % ntn) * F_BN;
+    A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC;
+    if (e.res) e.res = (const float*)e.res + blockIdx.y * e.sRes;
+    if (e.aux) e.aux = (float*)e.aux + blockIdx.y * e.sAux;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int64_t k0 = 0; k0 < K; k0 += F_BK) {
+        f32_stage<A_R>(As, A, lda, m0, k0, M, K, a_vec, tid);
+        f32_stage<B_R>(Bs, B, ldb, n0, k0, N, K, b_vec, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < F_BK; kk += 2) {
+            const int kr = kk + (lane >> 5), c = lane & 31;
+            float a[2], b[2];
+            a[0] = As[kr][wm + c]; a[1] = As[kr][wm + 32 + c];
+            b[0] = Bs[kr][wn + c]; b[1] = Bs[kr][wn + 32 + c];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t n = n0 + wn + j * 32 + (lane & 31);
+                if (m < M && n < N) epi_store<float>(e, C, ldc, m, n, acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 kernel
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int H_BM = 128, H_BN = 128, H_BK = 64;
+constexpr int H_LDK = H_BK + 8;    // form K tile: [128 rows][64 k] padded to 72 elements (144 B rows, 16-B aligned)
+constexpr int H_LDR = H_BM + 8;    // form R tile: [64 k][128 rows] padded to 136 elements (272 B rows, 16-B aligned)
+constexpr int H_TILE = (H_BM * H_LDK > H_BK * H_LDR ? H_BM * H_LDK : H_BK * H_LDR);   // elements per operand tile
+
+struct Stage4 { uint4 v[4]; };
+
+// global -> registers (4 x 16 B per thread per operand).  Out-of-range rows / k are zero-filled.
+template <bool FORM_R>
+__device__ __forceinline__ void h_load(Stage4& s, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
+                                       int64_t K, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        int64_t gr, gk;
+        bool ok;
+        const bf16* src;
+        if (FORM_R) { const int k = p >> 4, rq = (p & 15) * 8; gk = k0 + k; gr = r0 + rq; ok = gk < K && gr + 7 < R; src = X + gk * ld + gr; }
+        else        { const int row = p >> 3, kq = (p & 7) * 8; gr = r0 + row; gk = k0 + kq; ok = gr < R && gk + 7 < K; src = X + gr * ld + gk; }
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) v = *(const uint4*)src;
+        else {
+            // ragged edge: element-wise (rare: last tile of M/N/K only)
+            bf16 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool in;
+                if (FORM_R) in = gk < K && gr + j < R; else in = gr < R && gk + j < K;
+                t[j] = in ? src[j] : (bf16)0.f;
+            }
+            v = *(uint4*)t;
+        }
+        s.v[i] = v;
+    }
+}
+
+template <bool FORM_R>
+__device__ __forceinline__ void h_store(bf16* __restrict__ S, const Stage4& s, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        if (FORM_R) { const int k = p >> 4, rq = (p & 15) * 8; *(uint4*)&S[k * H_LDR + rq] = s.v[i]; }
+        else        { const int row = p >> 3, kq = (p & 7) * 8; *(uint4*)&S[row * H_LDK + kq] = s.v[i]; }
+    }
+}
+
+// MFMA 16x16x32 operand fragment of rows [rbase, rbase+16), k in [ks, ks+32) of one LDS tile.
+// lane l holds X[row = l&15][k = 8*(l>>4) + j], j = 0..7.
+template <bool FORM_R>
+__device__ __forceinline__ bf16x8 h_frag(const bf16* __restrict__ S, int rbase, int ks, int lane) {
+    if (!FORM_R) {
+        return *(const bf16x8*)&S[(rbase + (lane & 15)) * H_LDK + ks + 8 * (lane >> 4)];
+    } else {
+        // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of block row q, columns 4p..4p+3 of a
+        // 4-row x 16-column block of 16-bit elements; lane i receives column i, rows 0..3.  Block rows = k, columns = r.
+        // Group g = lane>>4 needs k = ks + 8g + {0..3} (first read) and + {4..7} (second read).
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const unsigned a0 = (unsigned)(uintptr_t)&S[(ks + 8 * g + q) * H_LDR + rbase + 4 * pp];
+        const unsigned a1 = a0 + 4u * H_LDR * (unsigned)sizeof(bf16);
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+template <bool A_R, bool B_R>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
+                                                        const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                        Epi e, int64_t ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* smem = (bf16*)smem_raw;                        // [2 buffers][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (wg / ntn) * H_BM, n0 = (wg % ntn) * H_BN;
+    A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
+    if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
+    if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t nk = (K + H_BK - 1) / H_BK;
+    Stage4 ra, rb;
+    h_load<A_R>(ra, A, lda, m0, 0, M, K, tid);
+    h_load<B_R>(rb, B, ldb, n0, 0, N, K, tid);
+    h_store<A_R>(smem, ra, tid);
+    h_store<B_R>(smem + H_TILE, rb, tid);
+    __syncthreads();
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const bf16* As = smem + (kt & 1) * 2 * H_TILE;
+        const bf16* Bs = As + H_TILE;
+        if (kt + 1 < nk) {
+            h_load<A_R>(ra, A, lda, m0, (kt + 1) * H_BK, M, K, tid);
+            h_load<B_R>(rb, B, ldb, n0, (kt + 1) * H_BK, N, K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < H_BK; ks += 32) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = h_frag<A_R>(As, wm + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = h_frag<B_R>(Bs, wn + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            bf16* An = smem + ((kt + 1) & 1) * 2 * H_TILE;
+            h_store<A_R>(An, ra, tid);
+            h_store<B_R>(An + H_TILE, rb, tid);
+        }
+        __syncthreads();
+    }
+    // C/D map of 16x16: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+                const int64_t n = n0 + wn + 16 * j + (lane & 15);
+                if (m < M && n < N) epi_store<bf16>(e, C, ldc, m, n, acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// optional per-launch HIP-event timing (bench.py's roofline figure is measured with these, on the launch stream)
+// ------------------------------------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; double flops; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+
+extern "C" int dvlp_prof_enable(int on) {
+    g_prof = on != 0;
+    return DVLP_OK;
+}
+// Synchronises; returns the summed duration (ms), flops and count of the GEMM launches recorded since the last call.
+extern "C" int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count) {
+    double ms = 0, fl = 0;
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        ms += t; fl += r.flops;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    *total_ms = ms; *total_flops = fl; *count = (int64_t)g_recs.size();
+    g_recs.clear();
+    return DVLP_OK;
+}
+
+extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                                 const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                                 void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
+                                 int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return DVLP_ERR_SHAPE;
+    if ((flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD)) && !aux) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    Epi e{bias, res, aux, ldres, ldaux, flags, alpha, strideA, strideB, strideC, strideRes, strideAux};
+    ProfRec rec{};
+    if (g_prof) { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); rec.flops = 2.0 * M * N * K * batch; (void)hipEventRecord(rec.a, st); }
+    if (dtype == DVLP_F32) {
+        const int64_t ntm = cdiv(M, F_BM), ntn = cdiv(N, F_BN);
+        const int a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0) && (strideA % 4 == 0);
+        const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0) && (strideB % 4 == 0);
+        dim3 grid((unsigned)(ntm * ntn), (unsigned)batch), block(256);
+#define LAUNCH_F32(AR, BR) hipLaunchKernelGGL((gemm_f32_kernel<AR, BR>), grid, block, 0, st, M, N, K, (const float*)A, lda, \
+                                              (const float*)B, ldb, (float*)C, ldc, e, a_vec, b_vec, ntn)
+        if (!transA && !transB) LAUNCH_F32(false, false);
+        else if (!transA && transB) LAUNCH_F32(false, true);
+        else if (transA && transB) LAUNCH_F32(true, true);
+        else LAUNCH_F32(true, false);
+#undef LAUNCH_F32
+    } else if (dtype == DVLP_BF16) {
+        // 16-byte vector loads need 8-element-aligned leading dims and base pointers
+        if (lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16 || strideA % 8 || strideB % 8) return DVLP_ERR_SHAPE;
+        const int64_t ntm = cdiv(M, H_BM), ntn = cdiv(N, H_BN);
+        dim3 grid((unsigned)(ntm * ntn), (unsigned)batch), block(256);
+        const size_t lds = (size_t)4 * H_TILE * sizeof(bf16);
+        // > 64 KiB of dynamic LDS must be opted into once per kernel
+#define LAUNCH_BF16(AR, BR) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
+        hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn); } while (0)
+        if (!transA && !transB) LAUNCH_BF16(false, false);
+        else if (!transA && transB) LAUNCH_BF16(false, true);
+        else if (transA && transB) LAUNCH_BF16(true, true);
+        else LAUNCH_BF16(true, false);
+#undef LAUNCH_BF16
+    } else {
+        return DVLP_ERR_DTYPE;
+    }
+    if (g_prof) { (void)hipEventRecord(rec.b, st); g_recs.push_back(rec); }
+    return dvlp_launch_status();
+}
+
+extern "C" int dvlp_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                         const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                         void* aux, int64_t ldaux, int flags, float alpha, void* stream) {
+    return dvlp_gemm_batched(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldres, aux, ldaux, flags, alpha, 1, 0, 0,
+                             0, 0, 0, stream);
+}

@@ -1,0 +1,165 @@
+// Loss heads on [B,B] similarity matrices: sim_matrix + NormSoftmaxLoss (K9/K10; model/model.py:582-590,
+// model/loss.py:126-138) and RWALoss's softmax-KL tail (K12; model/loss.py:105-116), forward AND analytic backward in
+// one launch.  B is the per-rank batch (64) or the gathered batch (<= 1024): latency-bound, one 1024-thread workgroup,
+// phases separated by workgroup barriers, all math fp32.
+#include "common.h"
+
+constexpr int LD_ = 256;   // embedding dim
+
+template <typename T> __device__ __forceinline__ void l4(const T* p, float (&o)[4]);
+template <> __device__ __forceinline__ void l4<float>(const float* p, float (&o)[4]) { float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void l4<bf16>(const bf16* p, float (&o)[4]) { bf16x4 v = *(const bf16x4*)p; o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+template <typename T> __device__ __forceinline__ void s4(T* p, const float (&o)[4]);
+template <> __device__ __forceinline__ void s4<float>(float* p, const float (&o)[4]) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
+template <> __device__ __forceinline__ void s4<bf16>(bf16* p, const float (&o)[4]) { bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3]; *(bf16x4*)p = v; }
+
+struct LossArgs {
+    const void *gt, *go;     // global text / object embeddings [Bt][256], [Bo][256]
+    const float* xs;         // local scores [Bo][Bt] (row = video) or null
+    float *sim, *dsim;       // [Bt][Bo] out / scratch
+    void *dgt, *dgo;         // grads (compute dtype)
+    float* dxs;              // [Bo][Bt] grad of the total loss wrt xs
+    float* losses;           // [3] total, global, local
+    int B;
+    float temperature, lam;
+    int use_global, use_local, stages;   // stages: 1 = sim forward, 2 = losses + dsim/dxs, 4 = embedding grads from dsim
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
+    extern __shared__ float sm[];
+    const int B = a.B, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float* nt = sm; float* no = nt + B; float* lse_r = no + B; float* lse_c = lse_r + B; float* red = lse_c + B;
+    const T* gt = (const T*)a.gt; const T* go = (const T*)a.go;
+    float gl = 0.f, ll = 0.f;
+    if (a.use_global && (a.stages & 5)) {
+        // norms, clamped as in sim_matrix: a / max(|a|, 1e-8)
+        for (int r = wid; r < 2 * B; r += nw) {
+            float v[4];
+            l4<T>((r < B ? gt + (int64_t)r * LD_ : go + (int64_t)(r - B) * LD_) + lane * 4, v);
+            const float n = sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+            if (lane == 0) (r < B ? nt[r] : no[r - B]) = fmaxf(n, 1e-8f);
+        }
+        __syncthreads();
+    }
+    if (a.use_global && (a.stages & 1)) {
+        // sim[t][o]: one wave per entry
+        for (int e = wid; e < B * B; e += nw) {
+            const int t = e / B, o = e % B;
+            float x[4], y[4];
+            l4<T>(gt + (int64_t)t * LD_ + lane * 4, x); l4<T>(go + (int64_t)o * LD_ + lane * 4, y);
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d += (x[c] / nt[t]) * (y[c] / no[o]);
+            d = wave_sum(d);
+            if (lane == 0) a.sim[e] = d;
+        }
+        __syncthreads();
+    }
+    if (a.use_global && (a.stages & 2)) {
+        // log-sum-exp of rows and columns of sim / temperature
+        for (int r = wid; r < 2 * B; r += nw) {
+            const bool row = r < B; const int idx = row ? r : r - B;
+            float m = -INFINITY;
+            for (int k = lane; k < B; k += 64) m = fmaxf(m, (row ? a.sim[idx * B + k] : a.sim[k * B + idx]) / a.temperature);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int k = lane; k < B; k += 64) s += expf((row ? a.sim[idx * B + k] : a.sim[k * B + idx]) / a.temperature - m);
+            s = wave_sum(s);
+            if (lane == 0) (row ? lse_r[idx] : lse_c[idx]) = m + logf(s);
+        }
+        __syncthreads();
+        float part = 0.f;
+        for (int e = threadIdx.x; e < B * B; e += blockDim.x) {
+            const int t = e / B, o = e % B;
+            const float z = a.sim[e] / a.temperature;
+            const float dl = (expf(z - lse_r[t]) + expf(z - lse_c[o]) - (t == o ? 2.f : 0.f)) / ((float)B * a.temperature);
+            a.dsim[e] = dl;
+            if (t == o) part -= (z - lse_r[t]) + (z - lse_c[o]);
+        }
+        gl = block_sum(part, red) / (float)B;
+        __syncthreads();
+    }
+    if (a.use_global && (a.stages & 4)) {
+        // d/d normalised rows, then through a / max(|a|, eps)
+        for (int r = wid; r < 2 * B; r += nw) {
+            const bool row = r < B; const int idx = row ? r : r - B;
+            const T* self = (row ? gt : go) + (int64_t)idx * LD_ + lane * 4;
+            const T* other = row ? go : gt;
+            const float* on = row ? no : nt;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < B; ++k) {
+                const float w = (row ? a.dsim[idx * B + k] : a.dsim[k * B + idx]) / on[k];
+                float y[4];
+                l4<T>(other + (int64_t)k * LD_ + lane * 4, y);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += w * y[c];
+            }
+            float x[4];
+            l4<T>(self, x);
+            const float n = row ? nt[idx] : no[idx];
+            float o4[4];
+            if (n > 1e-8f) {
+                const float proj = wave_sum(acc[0] * x[0] + acc[1] * x[1] + acc[2] * x[2] + acc[3] * x[3]) / (n * n);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o4[c] = (acc[c] - x[c] * proj) / n;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o4[c] = acc[c] / 1e-8f;
+            }
+            s4<T>((T*)(row ? a.dgt : a.dgo) + (int64_t)idx * LD_ + lane * 4, o4);
+        }
+    }
+    if (a.use_local && (a.stages & 2)) {
+        // RWA: p = softmax(lam * xs, dim=1); L_i = sum_j p (log p - log(eye + 1e-6)); dL_i/dz_k = p_k ((log p_k - c_k) - L_i)
+        float part = 0.f;
+        for (int i = wid; i < B; i += nw) {
+            float m = -INFINITY;
+            for (int k = lane; k < B; k += 64) m = fmaxf(m, a.xs[i * B + k] * a.lam);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int k = lane; k < B; k += 64) s += expf(a.xs[i * B + k] * a.lam - m);
+            const float lse = m + logf(wave_sum(s));
+            float Li = 0.f;
+            for (int k = lane; k < B; k += 64) {
+                const float lp = a.xs[i * B + k] * a.lam - lse;
+                Li += expf(lp) * (lp - logf((k == i ? 1.f : 0.f) + 1e-6f));
+            }
+            Li = wave_sum(Li);
+            for (int k = lane; k < B; k += 64) {
+                const float lp = a.xs[i * B + k] * a.lam - lse;
+                a.dxs[i * B + k] = a.lam / (float)B * expf(lp) * ((lp - logf((k == i ? 1.f : 0.f) + 1e-6f)) - Li);
+            }
+            if (lane == 0) part += Li;
+        }
+        ll = block_sum(part, red) / (float)B;
+    }
+    if (threadIdx.x == 0 && (a.stages & 2)) { a.losses[0] = gl + ll; a.losses[1] = gl; a.losses[2] = ll; }
+}
+
+// sim / dsim: fp32 [B*B] each.  stages (bitmask): 1 = sim_matrix forward (gt, go -> sim); 2 = losses from sim / xs, with
+// dsim = d global / d sim and dxs = d local / d xs; 4 = sim_matrix backward (dsim -> dgt, dgo).  7 = everything in one launch.
+extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,
+                                      float lam, int use_global, int use_local, int stages, float* sim, float* dsim, void* dgt, void* dgo,
+                                      float* dxs, float* losses, void* stream) {
+    if (d != LD_ || B <= 0 || B > 2048) return DVLP_ERR_SHAPE;
+    if (use_local && !xs) return DVLP_ERR_SHAPE;
+    LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages};
+    const size_t lds = (size_t)(4 * B + 32) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(loss_kernel<float>, dim3(1), dim3(1024), lds, st, a);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(loss_kernel<bf16>, dim3(1), dim3(1024), lds, st, a);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}

@@ -1,0 +1,194 @@
+// LayerNorm forward/backward and column reductions (bias gradients).  HBM-bound: one wave per row, 8/16-byte vector
+// accesses, statistics in fp32, two-stage deterministic column reductions (no float atomics).
+#include "common.h"
+
+constexpr int LN_MAXC = 4;   // D = 256 * NC, NC <= 4  (D = 768 on this path)
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&o)[4]) { float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&o)[4]) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct Vec4<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&o)[4]) { bf16x4 v = *(const bf16x4*)p; o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+    static __device__ __forceinline__ void store(bf16* p, const float (&o)[4]) { bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3]; *(bf16x4*)p = v; }
+};
+
+// y = (x - mean) * rstd * gamma + beta ; optional y_relu = max(y, 0)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int64_t M, int NC, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y, T* __restrict__ y_relu,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D = NC * 256;
+    float v[LN_MAXC][4];
+    float s = 0.f;
+    for (int c = 0; c < NC; ++c) {
+        Vec4<T>::load(x + row * D + c * 256 + lane * 4, v[c]);
+        s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    for (int c = 0; c < NC; ++c) {
+        float g[4], b[4], o[4];
+        Vec4<float>::load(gamma + c * 256 + lane * 4, g);
+        Vec4<float>::load(beta + c * 256 + lane * 4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
+        Vec4<T>::store(y + row * D + c * 256 + lane * 4, o);
+        if (y_relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+            Vec4<T>::store(y_relu + row * D + c * 256 + lane * 4, o);
+        }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma ;  partial dgamma/dbeta per block.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t M, int NC, const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const T* __restrict__ dres, T* __restrict__ dx,
+                                                     float* __restrict__ partial /* [grid][2][D] */) {
+    __shared__ float red[4][2][LN_MAXC * 256];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int D = NC * 256;
+    float dg[LN_MAXC][4], db[LN_MAXC][4], gm[LN_MAXC][4];
+    for (int c = 0; c < NC; ++c) {
+        Vec4<float>::load(gamma + c * 256 + lane * 4, gm[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[LN_MAXC][4], g[LN_MAXC][4];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = 0; c < NC; ++c) {
+            float d[4];
+            Vec4<T>::load(dy + row * D + c * 256 + lane * 4, d);
+            Vec4<T>::load(x + row * D + c * 256 + lane * 4, xh[c]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[c][j] = (xh[c][j] - mean) * rstd;
+                g[c][j] = d[j] * gm[c][j];
+                s1 += g[c][j];
+                s2 += g[c][j] * xh[c][j];
+                dg[c][j] += d[j] * xh[c][j];
+                db[c][j] += d[j];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        for (int c = 0; c < NC; ++c) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (g[c][j] - s1 - xh[c][j] * s2);
+            if (dres) {
+                float r[4];
+                Vec4<T>::load(dres + row * D + c * 256 + lane * 4, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += r[j];
+            }
+            Vec4<T>::store(dx + row * D + c * 256 + lane * 4, o);
+        }
+    }
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[wid][0][c * 256 + lane * 4 + j] = dg[c][j]; red[wid][1][c * 256 + lane * 4 + j] = db[c][j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int w = i / D, col = i % D;
+        partial[(int64_t)blockIdx.x * 2 * D + i] = red[0][w][col] + red[1][w][col] + red[2][w][col] + red[3][w][col];
+    }
+}
+
+// out[c] (+)= sum_p in[p*C + c]
+__global__ void reduce_rows_kernel(int64_t P, int64_t C, const float* __restrict__ in, float* __restrict__ out, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int64_t p = 0; p < P; ++p) s += in[p * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// stage 1 of a (grouped) column sum.  Row m of group g lives at x + g*gstride + (m / inner)*ostride + (m % inner)*ld.
+// partial[g][p][n] = sum over the p-th row chunk of x[row][n]
+template <typename T>
+__global__ void colsum_kernel(int64_t M, int64_t N, const T* __restrict__ x, int64_t ld, int64_t inner, int64_t ostride, int64_t gstride,
+                              int64_t rows_per, float* __restrict__ partial) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t g = blockIdx.z;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
+    const T* base = x + g * gstride;
+    float s = 0.f;
+    for (int64_t m = m0; m < m1; ++m) s += to_f(base[(m / inner) * ostride + (m % inner) * ld + n]);
+    partial[(g * gridDim.y + blockIdx.y) * N + n] = s;
+}
+
+// out[g][c] (+)= sum_p in[(g*P + p)*C + c]
+__global__ void reduce_groups_kernel(int64_t P, int64_t C, const float* __restrict__ in, float* __restrict__ out, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int64_t g = blockIdx.y;
+    float s = 0.f;
+    for (int64_t p = 0; p < P; ++p) s += in[(g * P + p) * C + c];
+    out[g * C + c] = accumulate ? out[g * C + c] + s : s;
+}
+
+extern "C" int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps,
+                                  void* y, void* y_relu, float* mean, float* rstd, void* stream) {
+    if (D % 256 || D > 256 * LN_MAXC || M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(M, 4)), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, (int)(D / 256), (const float*)x, gamma, beta, eps, (float*)y, (float*)y_relu, mean, rstd);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, st, M, (int)(D / 256), (const bf16*)x, gamma, beta, eps, (bf16*)y, (bf16*)y_relu, mean, rstd);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+// workspace: fp32 [(dvlp_layernorm_bwd_blocks(M) + 1) * 2 * D].  dgamma/dbeta are overwritten (accumulate=0) or added to.
+extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv(M, 4); return b < 512 ? b : 512; }
+
+extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
+                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace,
+                                  int accumulate, void* stream) {
+    if (D % 256 || D > 256 * LN_MAXC || M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = dvlp_layernorm_bwd_blocks(M);
+    dim3 grid((unsigned)nb), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, M, (int)(D / 256), (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, workspace);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, st, M, (int)(D / 256), (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, workspace);
+    else return DVLP_ERR_DTYPE;
+    // partial layout [nb][2][D]: reduce the two halves separately (stride 2D between blocks)
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv(2 * D, 256)), dim3(256), 0, st, nb, 2 * D, workspace, workspace + nb * 2 * D, 0);
+    // workspace tail [2D] now holds dgamma | dbeta
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv(D, 256)), dim3(256), 0, st, (int64_t)1, D, workspace + nb * 2 * D, dgamma, accumulate);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv(D, 256)), dim3(256), 0, st, (int64_t)1, D, workspace + nb * 2 * D + D, dbeta, accumulate);
+    return dvlp_launch_status();
+}
+
+// out[g][n] (+)= sum_m x_g[m][n]   (bias / embedding-table gradients).  Row m of group g is at
+// x + g*gstride + (m / inner)*ostride + (m % inner)*ld  (plain [M, ld] matrix: inner = M, groups = 1).
+// workspace: fp32 [groups * dvlp_colsum_chunks(M) * N]
+extern "C" int64_t dvlp_colsum_chunks(int64_t M) { const int64_t c = cdiv(M, 64); return c < 256 ? c : 256; }
+
+extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
+                           int64_t gstride, float* out, float* workspace, int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || groups <= 0 || inner <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = dvlp_colsum_chunks(M), rows_per = cdiv(M, P);
+    dim3 grid((unsigned)cdiv(N, 256), (unsigned)P, (unsigned)groups), block(256);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, M, N, (const float*)x, ld, inner, ostride, gstride, rows_per, workspace);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)x, ld, inner, ostride, gstride, rows_per, workspace);
+    else return DVLP_ERR_DTYPE;
+    hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(N, 256), (unsigned)groups), dim3(256), 0, st, P, N, workspace, out, accumulate);
+    return dvlp_launch_status();
+}

@@ -1,0 +1,509 @@
+// Local (region <-> word) cross-attention similarity, forward and backward (K11 of SURVEY.md section 2.2;
+// model/loss.py:209-330 restated per section 8(a) row A10).
+//
+// Round-1 structure: the three contractions of the forward (S = C^ Q^T, wc = P' C^, wc2 = P2' Q^) and the six of the
+// backward run as BATCHED calls of this library's MFMA GEMM over all pairs at once; the per-pair softmax / focal gate
+// / cosine work runs in LDS-tiled kernels (one workgroup per (video i, caption j) pair, S_ij staged once in LDS and
+// used for both directions).  Compared with the reference this computes S once (not twice), never materialises fp64,
+// and keeps every intermediate in the compute dtype.  All per-element math is fp32.
+//
+// Workspace tensors (T = compute dtype; Wp = W rounded up to 8, Gp = G rounded up to 8; pads are zero):
+//   Chat [Bi][G][d]   Qhat [Bj][Wp][d]          l2-normalised inputs  (x / (|x| + 1e-8), loss.py:333-338)
+//   S    [Bi][G][Bj][Wp]                          LeakyReLU_0.1(C^ Q^T);   backward overwrites it with dS_raw
+//   P1   [Bi][Bj][Wp][Gp]                         image->text re-normalised attention (softmax over regions)
+//   P2   [Bj][Bi][G][Wp]                          text->image re-normalised attention (softmax over words)
+//   wc   [Bi][Bj][Wp][d]   wc2 [Bj][Bi][G][d]     weighted contexts;        backward overwrites them with d wc / d wc2
+//   st1  [Bi][Bj][Wp][2]   st2 [Bj][Bi][G][2]     (dot, |wc|) per row, fp32
+//   dP1, dP2                                      backward only, same shapes as P1, P2 (then reused for D1, D2)
+#include "common.h"
+
+constexpr int XD = 256;   // projection_dim (model/model.py:65)
+
+extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                                 const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                                 void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
+                                 int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
+
+static inline int64_t rup(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
+
+struct XLayout {
+    int64_t Bi, Bj, G, W, Gp, Wp, es;   // es = element size
+    int64_t off_chat, off_qhat, off_S, off_P1, off_P2, off_wc, off_wc2, off_st1, off_st2, off_dP1, off_dP2, off_dchat, off_dqhat,
+        off_dirc, off_dirq, total;
+};
+static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
+    XLayout L{};
+    L.Bi = Bi; L.Bj = Bj; L.G = G; L.W = W; L.Gp = rup(G, 8); L.Wp = rup(W, 8); L.es = dtype == DVLP_F32 ? 4 : 2;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t r = o; o += rup(bytes, 256); return r; };
+    L.off_chat = take(Bi * G * XD * L.es);
+    L.off_qhat = take(Bj * L.Wp * XD * L.es);
+    L.off_S = take(Bi * G * Bj * L.Wp * L.es);
+    L.off_P1 = take(Bi * Bj * L.Wp * L.Gp * L.es);
+    L.off_P2 = take(Bj * Bi * G * L.Wp * L.es);
+    L.off_wc = take(Bi * Bj * L.Wp * XD * L.es);
+    L.off_wc2 = take(Bj * Bi * G * XD * L.es);
+    L.off_st1 = take(Bi * Bj * L.Wp * 2 * 4);
+    L.off_st2 = take(Bj * Bi * G * 2 * 4);
+    if (bwd) {
+        L.off_dP1 = take(Bi * Bj * L.Wp * L.Gp * L.es);
+        L.off_dP2 = take(Bj * Bi * G * L.Wp * L.es);
+        L.off_dchat = take(Bi * G * XD * L.es);
+        L.off_dqhat = take(Bj * L.Wp * XD * L.es);
+        L.off_dirc = take(Bi * G * XD * 4);
+        L.off_dirq = take(Bj * W * XD * 4);
+    }
+    L.total = o;
+    return L;
+}
+
+extern "C" int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
+    return xlayout(dtype, Bi, Bj, G, W, bwd).total;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// row helpers: a wave owns one 256-wide row, 4 channels per lane
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&o)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o)[4]) { float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void ld4<bf16>(const bf16* p, float (&o)[4]) { bf16x4 v = *(const bf16x4*)p; o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4]) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
+template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&o)[4]) { bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3]; *(bf16x4*)p = v; }
+
+// hat[row'] = raw[row] / (|raw[row]| + 1e-8); rows are remapped (r / inner) * inner_p + r % inner, pad rows zeroed
+template <typename T>
+__global__ __launch_bounds__(256) void xprep_kernel(int64_t outer, int64_t inner, int64_t inner_p, const T* __restrict__ raw, T* __restrict__ hat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= outer * inner_p) return;
+    const int64_t o = r / inner_p, in = r % inner_p;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in < inner) {
+        ld4<T>(raw + (o * inner + in) * XD + lane * 4, v);
+        const float n = sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3])) + 1e-8f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] / n;
+    }
+    st4<T>(hat + r * XD + lane * 4, v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-pair softmax stage.  LDS: Ssm [G][Wq] fp32 (Wq odd -> conflict-free column walks), rn [G], cn [W] (+ dots in bwd)
+// ------------------------------------------------------------------------------------------------------------------
+struct PairArgs {
+    void *S, *P1, *P2, *dP1, *dP2;
+    const float *mimg, *mcap;     // [Bi][G], [Bj][W] additive masks
+    int Bi, Bj, G, W, Gp, Wp, Wq;
+    float lam;
+    int gate;
+};
+
+template <typename T>
+__device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, float* Ssm, float* rn, float* cn) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const T* S = (const T*)a.S;
+    for (int g = wid; g < a.G; g += 4) {
+        const T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
+        float q = 0.f;
+        for (int w = lane; w < a.W; w += 64) { const float v = to_f(row[w]); Ssm[g * a.Wq + w] = v; q += v * v; }
+        q = wave_sum(q);
+        if (lane == 0) rn[g] = sqrtf(q) + 1e-8f;                       // l2norm over words (loss.py:238)
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
+        float q = 0.f;
+        for (int g = 0; g < a.G; ++g) { const float v = Ssm[g * a.Wq + w]; q += v * v; }
+        cn[w] = sqrtf(q) + 1e-8f;                                       // l2norm over regions (second call of :238)
+    }
+    __syncthreads();
+}
+
+constexpr int XMAXK = 20;   // a wave covers up to 64*20 = 1280 softmax entries (G <= 1280, W <= 1280)
+
+// softmax over n entries held as e[k] on lane (idx = lane + 64k); returns P (pre-gate) in e, P' in pp; s = sum of gated P
+__device__ __forceinline__ void focal_softmax(float (&e)[XMAXK], float (&pp)[XMAXK], int n, int nk, int lane, int gate, float& s_out) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < XMAXK; ++k) if (k < nk) m = fmaxf(m, lane + 64 * k < n ? e[k] : -INFINITY);
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < XMAXK; ++k) if (k < nk) { e[k] = lane + 64 * k < n ? expf(e[k] - m) : 0.f; sum += e[k]; }
+    sum = wave_sum(sum);
+    float psum = 0.f;
+#pragma unroll
+    for (int k = 0; k < XMAXK; ++k) if (k < nk) { e[k] = e[k] / sum; psum += e[k]; }
+    psum = wave_sum(psum);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < XMAXK; ++k) if (k < nk) {
+        const float h = gate ? ((e[k] * (float)n - psum) > 0.f ? 1.f : 0.f) : 1.f;   // focal_equal (loss.py:274-283)
+        pp[k] = h * e[k];
+        s += pp[k];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < XMAXK; ++k) if (k < nk) pp[k] = pp[k] / s;
+    s_out = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xsoftmax_fwd_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = blockIdx.x, i = blockIdx.y;
+    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G;
+    pair_load_S<T>(a, i, j, Ssm, rn, cn);
+    T* P1 = (T*)a.P1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;
+    T* P2 = (T*)a.P2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;
+    const float* mimg = a.mimg + (int64_t)i * a.G;
+    const float* mcap = a.mcap + (int64_t)j * a.W;
+    const int nkg = (a.G + 63) / 64, nkw = (a.W + 63) / 64, nkgp = (a.Gp + 63) / 64, nkwp = (a.Wp + 63) / 64;
+    // image -> text: for each word, softmax over regions (the caption-mask term is constant along this axis)
+    for (int w = wid; w < a.Wp; w += 4) {
+        float e[XMAXK], pp[XMAXK], s;
+        if (w < a.W) {
+#pragma unroll
+            for (int k = 0; k < XMAXK; ++k) if (k < nkg) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
+            focal_softmax(e, pp, a.G, nkg, lane, a.gate, s);
+        }
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkgp) { const int g = lane + 64 * k; if (g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(w < a.W && g < a.G ? pp[k] : 0.f); }
+    }
+    // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
+    for (int g = wid; g < a.G; g += 4) {
+        float e[XMAXK], pp[XMAXK], s;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
+        focal_softmax(e, pp, a.W, nkw, lane, a.gate, s);
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkwp) { const int w = lane + 64 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+    }
+}
+
+// backward of the softmax stage; leaves dS_raw in S (see file header)
+template <typename T>
+__global__ __launch_bounds__(256) void xsoftmax_bwd_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = blockIdx.x, i = blockIdx.y;
+    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* rowdot = cn + a.W; float* coldot = rowdot + a.G;
+    for (int t = threadIdx.x; t < a.G; t += blockDim.x) rowdot[t] = 0.f;
+    for (int t = threadIdx.x; t < a.W; t += blockDim.x) coldot[t] = 0.f;
+    pair_load_S<T>(a, i, j, Ssm, rn, cn);
+    T* D1 = (T*)a.dP1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;     // in: dP1, out: dA / rn
+    T* D2 = (T*)a.dP2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;      // in: dP2, out: dA2 / cn
+    const float* mimg = a.mimg + (int64_t)i * a.G;
+    const float* mcap = a.mcap + (int64_t)j * a.W;
+    const int nkg = (a.G + 63) / 64, nkw = (a.W + 63) / 64;
+    for (int w = wid; w < a.W; w += 4) {
+        float e[XMAXK], pp[XMAXK], s;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkg) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
+        focal_softmax(e, pp, a.G, nkg, lane, a.gate, s);
+        float dpp[XMAXK], d1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkg) { const int g = lane + 64 * k; dpp[k] = g < a.G ? to_f(D1[(int64_t)w * a.Gp + g]) : 0.f; d1 += dpp[k] * pp[k]; }
+        d1 = wave_sum(d1);
+        float d2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkg) {
+            // P' = T / s, T = H P  ->  dP = H (dP' - <dP', P'>) / s   (H is a constant gate; pp > 0 <=> H = 1)
+            dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f;
+            d2 += dpp[k] * e[k];
+        }
+        d2 = wave_sum(d2);
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkg) {
+            const int g = lane + 64 * k;
+            if (g < a.G) {
+                const float dA = a.lam * e[k] * (dpp[k] - d2);           // softmax backward, times lambda
+                D1[(int64_t)w * a.Gp + g] = from_f<T>(dA / rn[g]);
+                atomicAdd(&rowdot[g], dA * Ssm[g * a.Wq + w]);
+            }
+        }
+    }
+    for (int g = wid; g < a.G; g += 4) {
+        float e[XMAXK], pp[XMAXK], s;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
+        focal_softmax(e, pp, a.W, nkw, lane, a.gate, s);
+        float dpp[XMAXK], d1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { const int w = lane + 64 * k; dpp[k] = w < a.W ? to_f(D2[(int64_t)g * a.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
+        d1 = wave_sum(d1);
+        float d2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f; d2 += dpp[k] * e[k]; }
+        d2 = wave_sum(d2);
+#pragma unroll
+        for (int k = 0; k < XMAXK; ++k) if (k < nkw) {
+            const int w = lane + 64 * k;
+            if (w < a.W) {
+                const float dA = a.lam * e[k] * (dpp[k] - d2);
+                D2[(int64_t)g * a.Wp + w] = from_f<T>(dA / cn[w]);
+                atomicAdd(&coldot[w], dA * Ssm[g * a.Wq + w]);
+            }
+        }
+    }
+    __syncthreads();
+    // A = S / rn with rn = |S_row| + eps:  dS = dA/rn - S <dA,S>_row / (rn^2 (rn - eps)); same along columns; then LeakyReLU'
+    T* S = (T*)a.S;
+    for (int g = wid; g < a.G; g += 4) {
+        const float r = rn[g], cr = rowdot[g] / (r * r * fmaxf(r - 1e-8f, 1e-30f));
+        T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
+        for (int w = lane; w < a.W; w += 64) {
+            const float c = cn[w], cc = coldot[w] / (c * c * fmaxf(c - 1e-8f, 1e-30f));
+            const float sv = Ssm[g * a.Wq + w];
+            const float ds = to_f(D1[(int64_t)w * a.Gp + g]) + to_f(D2[(int64_t)g * a.Wp + w]) - sv * (cr + cc);
+            row[w] = from_f<T>(sv > 0.f ? ds : 0.1f * ds);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// cosine stage
+// ------------------------------------------------------------------------------------------------------------------
+struct CosArgs {
+    const void *Craw, *Qraw;    // [Bi][G][d], [Bj][W][d]
+    void *wc, *wc2;
+    float *st1, *st2, *scores;
+    const float* dscores;
+    float *dirc, *dirq;
+    int Bi, Bj, G, W, Wp;
+};
+
+// (dot, |b|) of a raw row with a context row; returns cosine
+template <typename T>
+__device__ __forceinline__ float row_cos(const T* raw, const T* ctx, int lane, float& dot, float& nb) {
+    float x[4], y[4];
+    ld4<T>(raw + lane * 4, x); ld4<T>(ctx + lane * 4, y);
+    float d = 0.f, nx = 0.f, ny = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { d += x[t] * y[t]; nx += x[t] * x[t]; ny += y[t] * y[t]; }
+    d = wave_sum(d); nx = sqrtf(wave_sum(nx)); ny = sqrtf(wave_sum(ny));
+    dot = d; nb = ny;
+    return d / fmaxf(nx * ny, 1e-8f);                       // cosine_similarity (loss.py:286-291)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xcos_fwd_kernel(CosArgs a) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = blockIdx.x, i = blockIdx.y;
+    float acc1 = 0.f, acc2 = 0.f;
+    for (int w = wid; w < a.W; w += 4) {
+        const int64_t r = ((int64_t)i * a.Bj + j) * a.Wp + w;
+        float dot, nb;
+        acc1 += row_cos<T>((const T*)a.Qraw + ((int64_t)j * a.W + w) * XD, (const T*)a.wc + r * XD, lane, dot, nb);
+        if (lane == 0) { a.st1[r * 2] = dot; a.st1[r * 2 + 1] = nb; }
+    }
+    for (int g = wid; g < a.G; g += 4) {
+        const int64_t r = ((int64_t)j * a.Bi + i) * a.G + g;
+        float dot, nb;
+        acc2 += row_cos<T>((const T*)a.Craw + ((int64_t)i * a.G + g) * XD, (const T*)a.wc2 + r * XD, lane, dot, nb);
+        if (lane == 0) { a.st2[r * 2] = dot; a.st2[r * 2 + 1] = nb; }
+    }
+    if (lane == 0) red[wid] = acc1 / (float)a.W + acc2 / (float)a.G;       // means include padded rows (loss.py:318, 327)
+    __syncthreads();
+    if (threadIdx.x == 0) a.scores[(int64_t)i * a.Bj + j] = red[0] + red[1] + red[2] + red[3];
+}
+
+// For every caption row (j, w): direct gradient wrt the raw word row (summed over videos i) and d wc in place.
+// cos = dot / (nq * nw):  d/d raw = ctx/(nq nw) - dot raw/(nq^3 nw);   d/d ctx = raw/(nq nw) - dot ctx/(nq nw^3)
+template <typename T>
+__global__ __launch_bounds__(256) void xcos_bwd_q_kernel(CosArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // j*Wp + w
+    if (row >= (int64_t)a.Bj * a.Wp) return;
+    const int j = (int)(row / a.Wp), w = (int)(row % a.Wp);
+    float q[4] = {0.f, 0.f, 0.f, 0.f}, dir[4] = {0.f, 0.f, 0.f, 0.f};
+    float nq = 0.f;
+    if (w < a.W) {
+        ld4<T>((const T*)a.Qraw + ((int64_t)j * a.W + w) * XD + lane * 4, q);
+        nq = sqrtf(wave_sum(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+    }
+    for (int i = 0; i < a.Bi; ++i) {
+        const int64_t r = ((int64_t)i * a.Bj + j) * a.Wp + w;
+        T* ctx = (T*)a.wc + r * XD + lane * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < a.W) {
+            const float dot = a.st1[r * 2], nw = a.st1[r * 2 + 1];
+            const float dcos = a.dscores[(int64_t)i * a.Bj + j] / (float)a.W;
+            const float den = nq * nw;
+            if (den > 1e-8f) {
+                float c[4];
+                ld4<T>(ctx, c);
+                const float ka = dcos / den, kb = dcos * dot / (den * nq * nq), kc = dcos * dot / (den * nw * nw);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { dir[t] += ka * c[t] - kb * q[t]; o[t] = ka * q[t] - kc * c[t]; }
+            }
+        }
+        st4<T>(ctx, o);
+    }
+    if (w < a.W) *(float4*)(a.dirq + ((int64_t)j * a.W + w) * XD + lane * 4) = make_float4(dir[0], dir[1], dir[2], dir[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xcos_bwd_c_kernel(CosArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // i*G + g
+    if (row >= (int64_t)a.Bi * a.G) return;
+    const int i = (int)(row / a.G), g = (int)(row % a.G);
+    float q[4], dir[4] = {0.f, 0.f, 0.f, 0.f};
+    ld4<T>((const T*)a.Craw + row * XD + lane * 4, q);
+    const float nq = sqrtf(wave_sum(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+    for (int j = 0; j < a.Bj; ++j) {
+        const int64_t r = ((int64_t)j * a.Bi + i) * a.G + g;
+        T* ctx = (T*)a.wc2 + r * XD + lane * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const float dot = a.st2[r * 2], nw = a.st2[r * 2 + 1];
+        const float dcos = a.dscores[(int64_t)i * a.Bj + j] / (float)a.G;
+        const float den = nq * nw;
+        if (den > 1e-8f) {
+            float c[4];
+            ld4<T>(ctx, c);
+            const float ka = dcos / den, kb = dcos * dot / (den * nq * nq), kc = dcos * dot / (den * nw * nw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { dir[t] += ka * c[t] - kb * q[t]; o[t] = ka * q[t] - kc * c[t]; }
+        }
+        st4<T>(ctx, o);
+    }
+    *(float4*)(a.dirc + row * XD + lane * 4) = make_float4(dir[0], dir[1], dir[2], dir[3]);
+}
+
+// x^ = x / (n + eps):  dx = dx^/(n+eps) - x <dx^, x> / ((n+eps)^2 n)  + direct term
+template <typename T>
+__global__ __launch_bounds__(256) void xprep_bwd_kernel(int64_t outer, int64_t inner, int64_t inner_p, const T* __restrict__ raw,
+                                                        const T* __restrict__ dhat, const float* __restrict__ dir, T* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= outer * inner) return;
+    const int64_t rp = (r / inner) * inner_p + r % inner;
+    float x[4], g[4];
+    ld4<T>(raw + r * XD + lane * 4, x);
+    ld4<T>(dhat + rp * XD + lane * 4, g);
+    const float n = sqrtf(wave_sum(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]));
+    const float gx = wave_sum(g[0] * x[0] + g[1] * x[1] + g[2] * x[2] + g[3] * x[3]);
+    const float ne = n + 1e-8f, k = n > 0.f ? gx / (ne * ne * n) : 0.f;
+    const float4 d = *(const float4*)(dir + r * XD + lane * 4);
+    float o[4] = {g[0] / ne - x[0] * k + d.x, g[1] / ne - x[1] * k + d.y, g[2] / ne - x[2] * k + d.z, g[3] / ne - x[3] * k + d.w};
+    st4<T>(dx + r * XD + lane * 4, o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------------------------
+static size_t pair_lds(int64_t G, int64_t W, int bwd) {
+    const int64_t Wq = W | 1;
+    return (size_t)(G * Wq + G + W + (bwd ? G + W : 0)) * sizeof(float);
+}
+#define XG(...) do { int rc_ = dvlp_gemm_batched(__VA_ARGS__); if (rc_) return rc_; } while (0)
+
+extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
+                              const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd,
+                              void* stream) {
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAXK || W > 64 * XMAXK) return DVLP_ERR_SHAPE;
+    if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
+    if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;      // long-video (G > ~380) tiling: not in round 1
+    hipStream_t st = (hipStream_t)stream;
+    const XLayout L = xlayout(dtype, Bi, Bj, G, W, bwd);
+    char* ws = (char*)workspace;
+    void *chat = ws + L.off_chat, *qhat = ws + L.off_qhat, *S = ws + L.off_S, *P1 = ws + L.off_P1, *P2 = ws + L.off_P2,
+         *wc = ws + L.off_wc, *wc2 = ws + L.off_wc2;
+    const int64_t Wp = L.Wp, Gp = L.Gp;
+    dim3 b256(256);
+#define DT(K, ...) do { if (dtype == DVLP_F32) hipLaunchKernelGGL(K<float>, __VA_ARGS__); else hipLaunchKernelGGL(K<bf16>, __VA_ARGS__); } while (0)
+#define TP(p) (dtype == DVLP_F32 ? (void*)(p) : (void*)(p))
+    if (dtype == DVLP_F32) {
+        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (float*)chat);
+        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (float*)qhat);
+    } else {
+        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const bf16*)Craw, (bf16*)chat);
+        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (bf16*)qhat);
+    }
+    // S[i] [G x Bj*Wp] = LeakyReLU(Chat_i [G x d] . Qhat^T)
+    XG(dtype, 0, 0, G, Bj * Wp, XD, chat, XD, qhat, XD, S, Bj * Wp, nullptr, nullptr, 0, nullptr, 0, EPI_LEAKY, 1.f, Bi, G * XD, 0,
+       G * Bj * Wp, 0, 0, stream);
+    PairArgs pa{};
+    pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.mimg = mimg; pa.mcap = mcap;
+    pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
+    pa.lam = lam; pa.gate = gate;
+    {
+        const size_t lds = pair_lds(G, W, 0);
+        static bool o1 = false, o2 = false;
+        if (dtype == DVLP_F32) { if (!o1) { o1 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
+        else { if (!o2) { o2 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
+        DT(xsoftmax_fwd_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, lds, st, pa);
+    }
+    // wc[i] [(Bj*Wp) x d] = P1[i] [(Bj*Wp) x G] . Chat_i [G x d]
+    XG(dtype, 0, 1, Bj * Wp, XD, G, P1, Gp, chat, XD, wc, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, G * XD,
+       Bj * Wp * XD, 0, 0, stream);
+    // wc2[j] [(Bi*G) x d] = P2[j] [(Bi*G) x Wp] . Qhat_j [Wp x d]
+    XG(dtype, 0, 1, Bi * G, XD, Wp, P2, Wp, qhat, XD, wc2, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Wp * XD,
+       Bi * G * XD, 0, 0, stream);
+    CosArgs ca{};
+    ca.Craw = Craw; ca.Qraw = Qraw; ca.wc = wc; ca.wc2 = wc2; ca.st1 = (float*)(ws + L.off_st1); ca.st2 = (float*)(ws + L.off_st2);
+    ca.scores = scores; ca.Bi = (int)Bi; ca.Bj = (int)Bj; ca.G = (int)G; ca.W = (int)W; ca.Wp = (int)Wp;
+    DT(xcos_fwd_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, 0, st, ca);
+    return dvlp_launch_status();
+}
+
+// workspace must be the one dvlp_xattn_fwd(..., bwd=1) filled.  Outputs: dC [Bi][G][d], dQ [Bj][W][d] (compute dtype).
+extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
+                              const float* mimg, const float* mcap, float lam, int gate, const float* dscores, void* workspace,
+                              void* dC, void* dQ, void* stream) {
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAXK || W > 64 * XMAXK) return DVLP_ERR_SHAPE;
+    if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
+    if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const XLayout L = xlayout(dtype, Bi, Bj, G, W, 1);
+    char* ws = (char*)workspace;
+    void *chat = ws + L.off_chat, *qhat = ws + L.off_qhat, *S = ws + L.off_S, *P1 = ws + L.off_P1, *P2 = ws + L.off_P2,
+         *wc = ws + L.off_wc, *wc2 = ws + L.off_wc2, *dP1 = ws + L.off_dP1, *dP2 = ws + L.off_dP2, *dchat = ws + L.off_dchat,
+         *dqhat = ws + L.off_dqhat;
+    float *dirc = (float*)(ws + L.off_dirc), *dirq = (float*)(ws + L.off_dirq);
+    const int64_t Wp = L.Wp, Gp = L.Gp;
+    dim3 b256(256);
+    CosArgs ca{};
+    ca.Craw = Craw; ca.Qraw = Qraw; ca.wc = wc; ca.wc2 = wc2; ca.st1 = (float*)(ws + L.off_st1); ca.st2 = (float*)(ws + L.off_st2);
+    ca.dscores = dscores; ca.dirc = dirc; ca.dirq = dirq; ca.Bi = (int)Bi; ca.Bj = (int)Bj; ca.G = (int)G; ca.W = (int)W; ca.Wp = (int)Wp;
+    DT(xcos_bwd_q_kernel, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, ca);       // wc  <- d wc
+    DT(xcos_bwd_c_kernel, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, ca);        // wc2 <- d wc2
+    // dP1[i] [(Bj*Wp) x G] = dwc[i] [(Bj*Wp) x d] . Chat_i^T
+    XG(dtype, 0, 0, Bj * Wp, G, XD, wc, XD, chat, XD, dP1, Gp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * XD, G * XD,
+       Bj * Wp * Gp, 0, 0, stream);
+    // dP2[j] [(Bi*G) x Wp] = dwc2[j] [(Bi*G) x d] . Qhat_j^T
+    XG(dtype, 0, 0, Bi * G, Wp, XD, wc2, XD, qhat, XD, dP2, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * XD, Wp * XD,
+       Bi * G * Wp, 0, 0, stream);
+    PairArgs pa{};
+    pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.dP1 = dP1; pa.dP2 = dP2; pa.mimg = mimg; pa.mcap = mcap;
+    pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
+    pa.lam = lam; pa.gate = gate;
+    {
+        const size_t lds = pair_lds(G, W, 1);
+        static bool o1 = false, o2 = false;
+        if (dtype == DVLP_F32) { if (!o1) { o1 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
+        else { if (!o2) { o2 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
+        DT(xsoftmax_bwd_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, lds, st, pa);   // S <- dS_raw
+    }
+    // dChat_i [G x d] = P1[i]^T [G x Bj*Wp] . dwc[i] [Bj*Wp x d]  +  dSraw[i] [G x Bj*Wp] . Qhat [Bj*Wp x d]
+    XG(dtype, 1, 1, G, XD, Bj * Wp, P1, Gp, wc, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, Bj * Wp * XD,
+       G * XD, 0, 0, stream);
+    XG(dtype, 0, 1, G, XD, Bj * Wp, S, Bj * Wp, qhat, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bi, G * Bj * Wp, 0,
+       G * XD, 0, 0, stream);
+    // dQhat_j [Wp x d] = P2[j]^T [Wp x Bi*G] . dwc2[j] [Bi*G x d]  +  dSraw[:, :, j, :]^T [Wp x Bi*G] . Chat [Bi*G x d]
+    XG(dtype, 1, 1, Wp, XD, Bi * G, P2, Wp, wc2, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Bi * G * XD,
+       Wp * XD, 0, 0, stream);
+    XG(dtype, 1, 1, Wp, XD, Bi * G, S, Bj * Wp, chat, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bj, Wp, 0, Wp * XD, 0,
+       0, stream);
+    if (dtype == DVLP_F32) {
+        hipLaunchKernelGGL(xprep_bwd_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (const float*)dchat, dirc, (float*)dC);
+        hipLaunchKernelGGL(xprep_bwd_kernel<float>, dim3((unsigned)cdiv(Bj * W, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (const float*)dqhat, dirq, (float*)dQ);
+    } else {
+        hipLaunchKernelGGL(xprep_bwd_kernel<bf16>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const bf16*)Craw, (const bf16*)dchat, dirc, (bf16*)dC);
+        hipLaunchKernelGGL(xprep_bwd_kernel<bf16>, dim3((unsigned)cdiv(Bj * W, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (const bf16*)dqhat, dirq, (bf16*)dQ);
+    }
+    return dvlp_launch_status();
+}

@@ -1,0 +1,351 @@
+"""autograd.Function wrappers: one node per tower layer / loss head, each forward and backward a short, explicit
+sequence of C-ABI kernel launches (ops.py).  Layer-level nodes (rather than op-level) let the residual adds, GELU,
+bias and gradient accumulations live in GEMM / LayerNorm epilogues instead of separate element-wise launches, and give
+DDP-style hooks one firing point per layer for bucketed gradient all-reduce.
+
+Master parameters stay fp32; with ``compute dtype = bfloat16`` the GEMM weights are read from bf16 shadows kept by
+``SHADOWS`` (refreshed when the parameter's version counter moves, or written directly by the fused optimizer).
+Weight gradients are produced in fp32 straight from the MFMA epilogue.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class ShadowCache:
+    """bf16 copies of fp32 master weights for the MFMA kernels."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        if dtype == torch.float32:
+            return w.detach()
+        e = self._c.get(id(w))
+        if e is None or e[0] != w._version or e[1].dtype != dtype or e[2] != w.data_ptr():
+            dst = e[1] if (e is not None and e[1].dtype == dtype and e[1].shape == w.shape and not e[3]) else None
+            sh = ops.cast(w.detach(), dtype, out=dst)
+            e = (w._version, sh, w.data_ptr(), False)
+            self._c[id(w)] = e
+        return e[1]
+
+    def adopt(self, w: torch.Tensor, shadow_view: torch.Tensor):
+        """Register an externally maintained shadow (a view of the fused optimizer's flat bf16 buffer)."""
+        self._c[id(w)] = (w._version, shadow_view, w.data_ptr(), True)
+
+    def clear(self):
+        self._c.clear()
+
+
+SHADOWS = ShadowCache()
+
+
+def _grad_buf(param):
+    """fp32 gradient destination for a parameter: its slice of the flat gradient arena when one is attached."""
+    gv = getattr(param, "_dvlp_grad_view", None)
+    # a fresh view object each time: autograd's AccumulateGrad adopts (rather than clones) a gradient it solely owns
+    return gv.view(gv.shape) if gv is not None else None
+
+
+def _wgrad(dy2d, x2d, param):
+    return ops.linear_bwd_weight(dy2d, x2d, out=_grad_buf(param))
+
+
+def _bgrad(dy2d, param):
+    return ops.colsum(dy2d, out=_grad_buf(param))
+
+
+def _into(param, value):
+    """Place a small fp32 gradient into the parameter's arena slice (if any) and return the tensor to hand to autograd."""
+    gv = _grad_buf(param)
+    if gv is None:
+        return value.reshape(param.shape)
+    gv.copy_(value.reshape(param.shape))
+    return gv
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# generic linear (object_model.proj, txt_proj)
+# ----------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b.  With ``relu_src`` given, x must be relu(relu_src) and the gradient is returned for relu_src."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu_src):
+        cd = x.dtype
+        wc = SHADOWS.get(w, cd)
+        x2 = x.reshape(-1, x.shape[-1])
+        y = ops.linear_fwd(x2, wc, b.detach() if b is not None else None)
+        ctx.save_for_backward(x2, w, relu_src.reshape(x2.shape) if relu_src is not None else None)
+        ctx.has_b = b is not None
+        ctx.bparam = b
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, relu_src = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        wc = SHADOWS.get(w, x2.dtype)
+        dx = ops.linear_bwd_input(dy2, wc, relu_pre=relu_src)
+        dw = _wgrad(dy2, x2, w)
+        db = _bgrad(dy2, ctx.bparam) if ctx.has_b else None
+        dx = dx.reshape(ctx.in_shape)
+        if relu_src is not None:
+            return None, dw, db, dx
+        return dx, dw, db, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# object tower
+# ----------------------------------------------------------------------------------------------------------------
+class ObjectPrologueFn(torch.autograd.Function):
+    """model/object_transformer.py:400-433: region/box embedding, CLS, temporal embedding, additive mask."""
+
+    @staticmethod
+    def forward(ctx, obj, mask01, Wo, bo, Wp, bp, temporal, cls, pos_embed, cd):
+        B, F, R, _ = obj.shape
+        feat, box = ops.obj_split(obj, cd)
+        tok = ops.linear_fwd(feat, SHADOWS.get(Wo, cd), bo.detach())
+        pos0 = pos_embed.detach()[0, 0].contiguous()
+        x, addmask = ops.embed_assemble(tok, box, Wp.detach(), bp.detach(), temporal.detach().reshape(F, 768), cls.detach().reshape(768),
+                                        pos0, mask01, B, F, R)
+        ctx.save_for_backward(feat, box)
+        ctx.params = (Wo, bo, Wp, bp, temporal, cls, pos_embed)
+        ctx.dims = (B, F, R)
+        ctx.mark_non_differentiable(addmask)
+        return x.reshape(B, 1 + F * R, 768), addmask
+
+    @staticmethod
+    def backward(ctx, dx, _dmask):
+        feat, box = ctx.saved_tensors
+        Wo, bo, Wp, bp, temporal, cls, pos_embed = ctx.params
+        B, F, R = ctx.dims
+        N = 1 + F * R
+        dx = dx.contiguous()
+        dtok = ops.embed_unassemble(dx, B, F, R)
+        dWo = _wgrad(dtok, feat, Wo)
+        dbo = _bgrad(dtok, bo)
+        dbp = _into(bp, dbo.clone())                      # same sum: both biases are added to every region token
+        dWp = _into(Wp, ops.box_wgrad(dtok, box))
+        # temporal[f] = sum over (b, r) of dtok[b, f, r, :]
+        dtemp = ops.colsum_grouped(dtok, B * R, 768, 768, R, F * R * 768, F, R * 768)
+        dtemp = _into(temporal, dtemp.reshape(1, F, 768))
+        dcls_row = ops.colsum_grouped(dx, B, 768, N * 768, B, 0, 1, 0).reshape(768)     # sum_b dx[b, 0, :]
+        dcls = _into(cls, dcls_row.reshape(1, 1, 768))
+        dpos = torch.zeros_like(pos_embed)
+        dpos[0, 0] = dcls_row
+        dpos = _into(pos_embed, dpos)
+        return None, None, dWo, dbo, dWp, dbp, dtemp, dcls, dpos, None
+
+
+class VitBlockFn(torch.autograd.Function):
+    """SpaceTimeBlock with time_module falsy (model/object_transformer.py:249-274): pre-LN space attention + MLP."""
+
+    @staticmethod
+    def forward(ctx, x, addmask, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, F, R):
+        B, N, D = x.shape
+        cd = x.dtype
+        x2 = x.reshape(B * N, D)
+        h1, _, m1, r1 = ops.layernorm_fwd(x2, n1w.detach(), n1b.detach(), 1e-6)
+        qkv = ops.linear_fwd(h1, SHADOWS.get(qkvw, cd), qkvb.detach())
+        att = ops.space_attention_fwd(qkv, addmask, B, F, R)
+        x1 = ops.linear_fwd(att, SHADOWS.get(pw, cd), pb.detach(), res=x2)
+        h2, _, m2, r2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6)
+        pre = torch.empty((B * N, f1w.shape[0]), device=x.device, dtype=cd)
+        a = ops.linear_fwd(h2, SHADOWS.get(f1w, cd), f1b.detach(), gelu_aux=pre)
+        y = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach(), res=x1)
+        ctx.save_for_backward(x2, addmask, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a)
+        ctx.params = (n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.dims = (B, N, F, R)
+        return y.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, addmask, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a = ctx.saved_tensors
+        n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = ctx.params
+        B, N, F, R = ctx.dims
+        cd = x2.dtype
+        dy2 = dy.reshape(B * N, -1).contiguous()
+        df2b = _bgrad(dy2, f2b)
+        df2w = _wgrad(dy2, a, f2w)
+        dpre = ops.linear_bwd_input(dy2, SHADOWS.get(f2w, cd), gelu_pre=pre)
+        df1b = _bgrad(dpre, f1b)
+        df1w = _wgrad(dpre, h2, f1w)
+        dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
+        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w.detach(), m2, r2, dres=dy2)
+        dpb = _bgrad(dx1, pb)
+        dpw = _wgrad(dx1, att, pw)
+        datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
+        dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R)
+        dqkvb = _bgrad(dqkv, qkvb)
+        dqkvw = _wgrad(dqkv, h1, qkvw)
+        dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
+        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2, n1w.detach(), m1, r1, dres=dx1)
+        return (dx.reshape(B, N, -1), None, _into(n1w, dn1w), _into(n1b, dn1b), dqkvw, dqkvb, dpw, dpb, _into(n2w, dn2w),
+                _into(n2b, dn2b), df1w, df1b, df2w, df2b, None, None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# text tower (DistilBERT)
+# ----------------------------------------------------------------------------------------------------------------
+class TextEmbedFn(torch.autograd.Function):
+    """word + position embeddings -> LayerNorm(eps 1e-12).  padding_idx 0 receives no gradient."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, lnw, lnb, cd):
+        e, y, mean, rstd = ops.text_embed_fwd(ids, word.detach(), pos.detach(), lnw.detach(), lnb.detach(), 1e-12, cd)
+        ctx.save_for_backward(ids, e, mean, rstd)
+        ctx.params = (word, pos, lnw, lnb)
+        return y.reshape(ids.shape[0], ids.shape[1], 768)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, e, mean, rstd = ctx.saved_tensors
+        word, pos, lnw, lnb = ctx.params
+        B, L = ids.shape
+        dy2 = dy.reshape(B * L, 768).contiguous()
+        de, dg, db = ops.layernorm_bwd(dy2, e, lnw.detach(), mean, rstd)
+        gv = _grad_buf(word)
+        if gv is not None:
+            gv.zero_()
+            ops.call("dvlp_text_embed_bwd", ops.dt(de), B * L, ops.p(ids), ops.p(de), ops.p(gv), ops.stream())
+            dword = gv
+        else:
+            dword = ops.text_embed_bwd(ids, de, word.shape[0])
+        dpos = torch.zeros_like(pos)
+        dpos[:L] = ops.colsum_grouped(de, B, 768, L * 768, B, 0, L, 768)          # sum over the batch per position
+        return None, dword, _into(pos, dpos), _into(lnw, dg), _into(lnb, db), None
+
+
+class BertLayerFn(torch.autograd.Function):
+    """One DistilBERT TransformerBlock (post-LN, eps 1e-12, exact GELU).  ``want_relu``: also return relu(y)."""
+
+    @staticmethod
+    def forward(ctx, x, addmask, qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b, want_relu):
+        B, L, D = x.shape
+        cd = x.dtype
+        x2 = x.reshape(B * L, D)
+        q = ops.linear_fwd(x2, SHADOWS.get(qw, cd), qb.detach())
+        k = ops.linear_fwd(x2, SHADOWS.get(kw, cd), kb.detach())
+        v = ops.linear_fwd(x2, SHADOWS.get(vw, cd), vb.detach())
+        att = ops.full_attention_fwd(q, k, v, addmask, B, L)
+        s1 = ops.linear_fwd(att, SHADOWS.get(ow, cd), ob.detach(), res=x2)
+        x1, _, m1, r1 = ops.layernorm_fwd(s1, l1w.detach(), l1b.detach(), 1e-12)
+        pre = torch.empty((B * L, f1w.shape[0]), device=x.device, dtype=cd)
+        a = ops.linear_fwd(x1, SHADOWS.get(f1w, cd), f1b.detach(), gelu_aux=pre)
+        s2 = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach(), res=x1)
+        y, yr, m2, r2 = ops.layernorm_fwd(s2, l2w.detach(), l2b.detach(), 1e-12, want_relu=want_relu)
+        ctx.save_for_backward(x2, addmask, q, k, v, att, s1, m1, r1, x1, pre, a, s2, m2, r2)
+        ctx.params = (qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b)
+        ctx.dims = (B, L)
+        y = y.reshape(B, L, D)
+        if want_relu:
+            yr = yr.reshape(B, L, D)
+            ctx.mark_non_differentiable(yr)
+            return y, yr
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dyr):
+        x2, addmask, q, k, v, att, s1, m1, r1, x1, pre, a, s2, m2, r2 = ctx.saved_tensors
+        qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b = ctx.params
+        B, L = ctx.dims
+        cd = x2.dtype
+        dy2 = dy.reshape(B * L, -1).contiguous()
+        ds2, dl2w, dl2b = ops.layernorm_bwd(dy2, s2, l2w.detach(), m2, r2)
+        df2b = _bgrad(ds2, f2b)
+        df2w = _wgrad(ds2, a, f2w)
+        dpre = ops.linear_bwd_input(ds2, SHADOWS.get(f2w, cd), gelu_pre=pre)
+        df1b = _bgrad(dpre, f1b)
+        df1w = _wgrad(dpre, x1, f1w)
+        dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
+        ds1, dl1w, dl1b = ops.layernorm_bwd(dx1, s1, l1w.detach(), m1, r1)
+        dob = _bgrad(ds1, ob)
+        dow = _wgrad(ds1, att, ow)
+        datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))
+        dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, datt, B, L)
+        dqb, dkb, dvb = _bgrad(dq, qb), _bgrad(dk, kb), _bgrad(dv, vb)
+        dqw, dkw, dvw = _wgrad(dq, x2, qw), _wgrad(dk, x2, kw), _wgrad(dv, x2, vw)
+        dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
+        ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
+        ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)
+        return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, _into(l1w, dl1w), _into(l1b, dl1b), df1w, df1b,
+                df2w, df2b, _into(l2w, dl2w), _into(l2b, dl2b), None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------------------------
+class SimMatrixFn(torch.autograd.Function):
+    """model/model.py:582-590."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        r = ops.global_local_loss(a, b, None, 0.05, 20.0, 1, 0, 1)
+        ctx.save_for_backward(a, b)
+        return r["sim"]
+
+    @staticmethod
+    def backward(ctx, dsim):
+        a, b = ctx.saved_tensors
+        r = ops.global_local_loss(a, b, None, 0.05, 20.0, 1, 0, 4, dsim=dsim.contiguous().float())
+        return r["dgt"], r["dgo"]
+
+
+class NormSoftmaxFn(torch.autograd.Function):
+    """model/loss.py:126-138 on a given similarity matrix."""
+
+    @staticmethod
+    def forward(ctx, sim, temperature):
+        r = ops.global_local_loss(None, None, None, temperature, 20.0, 1, 0, 2, sim=sim.contiguous().float())
+        ctx.save_for_backward(r["dsim"])
+        return r["losses"][1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dsim,) = ctx.saved_tensors
+        return dsim * g, None
+
+
+class XattnFn(torch.autograd.Function):
+    """xattn_score_fast (model/loss.py:294-330): [n_img, n_cap] score matrix."""
+
+    @staticmethod
+    def forward(ctx, im, s, im_m, s_m, lam, gate):
+        im, s = im.contiguous(), s.contiguous()
+        im_m = im_m.contiguous().float()
+        s_m = s_m.contiguous().float()
+        need = im.requires_grad or s.requires_grad
+        scores, ws = ops.xattn_fwd(im, s, im_m, s_m, lam, gate, need)
+        if need:
+            ctx.save_for_backward(im, s, im_m, s_m)
+            ctx.ws = ws
+            ctx.cfg = (lam, gate)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        im, s, im_m, s_m = ctx.saved_tensors
+        lam, gate = ctx.cfg
+        dC, dQ = ops.xattn_bwd(im, s, im_m, s_m, lam, gate, dscores.contiguous().float(), ctx.ws)
+        ctx.ws = None
+        return dC, dQ, None, None, None, None
+
+
+class RWATailFn(torch.autograd.Function):
+    """model/loss.py:105-116 on a given score matrix."""
+
+    @staticmethod
+    def forward(ctx, scores, lam):
+        r = ops.global_local_loss(None, None, scores.contiguous().float(), 0.05, lam, 0, 1, 2)
+        ctx.save_for_backward(r["dxs"])
+        return r["losses"][2]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dxs,) = ctx.saved_tensors
+        return dxs * g, None

@@ -1,0 +1,109 @@
+"""ObjectTransformer: the region-feature video encoder (mirror of model/object_transformer.py:296-452).
+
+Same constructor arguments, parameter names/shapes (state_dict interchange) and forward contract as the reference;
+the arithmetic runs in hand-written gfx950 kernels (functional.py -> ops.py -> libdemovlp_hip.so).  Only the
+configuration every shipped DemoVLP config uses is implemented: ``time_module`` falsy (space attention only).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+EMBED, DEPTH, HIDDEN = 768, 12, 3072
+
+
+class _Affine(nn.Module):
+    """Holds LayerNorm parameters under the reference's names (weight, bias)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Linear(nn.Module):
+    def __init__(self, fin, fout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.zeros(fout)) if bias else None
+        nn.init.trunc_normal_(self.weight, std=0.02)
+
+
+class VarAttention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = _Linear(dim, dim * 3)
+        self.proj = _Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = _Linear(dim, hidden)
+        self.fc2 = _Linear(hidden, dim)
+
+
+class SpaceTimeBlock(nn.Module):
+    """model/object_transformer.py:199-274 with time_module falsy.  norm3 exists (and never gets a gradient), as in
+    the reference, so checkpoints interchange."""
+
+    def __init__(self, dim=EMBED, hidden=HIDDEN):
+        super().__init__()
+        self.norm1 = _Affine(dim)
+        self.attn = VarAttention(dim)
+        self.norm2 = _Affine(dim)
+        self.mlp = Mlp(dim, hidden)
+        self.norm3 = _Affine(dim)
+
+    def forward(self, x, addmask, frames, regions):
+        return Fn.VitBlockFn.apply(x, addmask, self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+                                   self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight, self.norm2.bias,
+                                   self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, frames, regions)
+
+
+class ObjectTransformer(nn.Module):
+    def __init__(self, input_dim=2054, region_nums=20, num_frames=4, output_dim=256, time_module=None):
+        super().__init__()
+        if time_module:
+            raise NotImplementedError("time_module='timeattn' is not used by any shipped DemoVLP config and is not "
+                                      "implemented on the MI355X path (SURVEY.md section 8(f) rank 4)")
+        if input_dim != 2054:
+            raise NotImplementedError("region features are 2048-d + 6-d box geometry")
+        self.num_frames = num_frames
+        self.embed_dim = self.num_features = EMBED
+        self.patches_per_frame = region_nums
+        self.feat_dim = 2048
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, EMBED))
+        self.custom_pos_embed = nn.Parameter(torch.zeros(1, region_nums + 1, EMBED))
+        self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, EMBED))
+        self.blocks = nn.ModuleList([SpaceTimeBlock() for _ in range(DEPTH)])
+        self.norm = _Affine(EMBED)            # defined and never applied (object_transformer.py:354, 446-452)
+        self.object_embedding = _Linear(self.feat_dim, EMBED)
+        self.pos_embedding = _Linear(input_dim - self.feat_dim, EMBED)
+        self.proj = _Linear(EMBED, output_dim, bias=False)
+        nn.init.trunc_normal_(self.custom_pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        self.compute_dtype = torch.float32
+
+    def forward_features(self, x, x_mask):
+        B, F, R, C = x.shape
+        if R != self.patches_per_frame:
+            raise ValueError(f"expected {self.patches_per_frame} regions per frame, got {R}")
+        if F > self.num_frames:
+            raise ValueError(f"{F} frames > temporal_embed size {self.num_frames}")
+        obj = x.contiguous().float()
+        mask01 = x_mask.reshape(B, F, R).contiguous().float()
+        temporal = self.temporal_embed if F == self.num_frames else self.temporal_embed[:, :F]
+        tok, addmask = Fn.ObjectPrologueFn.apply(obj, mask01, self.object_embedding.weight, self.object_embedding.bias,
+                                                 self.pos_embedding.weight, self.pos_embedding.bias, temporal, self.cls_token,
+                                                 self.custom_pos_embed, self.compute_dtype)
+        for blk in self.blocks:
+            tok = blk(tok, addmask, F, R)
+        return tok, addmask
+
+    def forward(self, x, x_mask):
+        """x [B,F,R,2054], x_mask [B,F,R] (1 = real region) -> (embeddings [B,N,256], additive mask [B,N])."""
+        tok, addmask = self.forward_features(x, x_mask)
+        return Fn.LinearFn.apply(tok, self.proj.weight, None, None), addmask

@@ -1,0 +1,321 @@
+"""Thin tensor-level wrappers over the C ABI (include/demovlp_hip.h).  No autograd here; see functional.py.
+
+Every function takes contiguous CUDA(HIP) tensors, launches on torch's current stream and returns torch tensors
+allocated with the caching allocator (PyTorch is plumbing for device memory and streams only).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_ACCUM, EPI_GELU, EPI_GELU_BWD, EPI_LEAKY, EPI_RELU_BWD, F32, call
+
+EPI_OUT_F32 = 32
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise _lib.DemoVLPHipError(f"unsupported compute dtype {d}") from None
+
+
+def p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.DemoVLPHipError("demovlp_amd kernels need tensors on an MI355X device (no CPU fallback)")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------------------------
+def gemm(a, b, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, out=None, ldc=None, bias=None, res=None,
+         aux=None, flags=0, alpha=1.0, out_f32=False, dtype=None):
+    """C[M,N] = epi(alpha * op(A) op(B)^T).  a/b/out/res/aux are tensors whose data_ptr is the matrix origin."""
+    d = dt(a) if dtype is None else dtype
+    lda = lda if lda is not None else (M if trans_a else K)
+    ldb = ldb if ldb is not None else (N if trans_b else K)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    ldc = ldc if ldc is not None else N
+    if out_f32:
+        flags |= EPI_OUT_F32
+    call("dvlp_gemm", d, int(trans_a), int(trans_b), M, N, K, p(a), lda, p(b), ldb, p(out), ldc, p(bias), p(res),
+         N if res is not None else 0, p(aux), N if aux is not None else 0, flags, float(alpha), stream())
+    return out
+
+
+def linear_fwd(x2d, w, bias=None, res=None, gelu_aux=None):
+    """y = x W^T (+ bias) (+ res); with gelu_aux given: aux <- pre-activation, y <- gelu(pre)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    return gemm(x2d, w, M, N, K, bias=bias, res=res, aux=gelu_aux, flags=EPI_GELU if gelu_aux is not None else 0)
+
+
+def linear_bwd_input(dy2d, w, *, res=None, gelu_pre=None, relu_pre=None, out=None, accumulate=False):
+    """dx = dy W  (optionally * gelu'(pre) or masked by pre > 0, + res, or accumulated onto ``out``)."""
+    M, N = dy2d.shape
+    K = w.shape[1]
+    flags, aux = 0, None
+    if gelu_pre is not None:
+        flags, aux = EPI_GELU_BWD, gelu_pre
+    elif relu_pre is not None:
+        flags, aux = EPI_RELU_BWD, relu_pre
+    if accumulate:
+        flags |= EPI_ACCUM
+    # A = dy [M x N] (k = N contiguous), B(kin, n) = W[n][kin] -> form R with ld = K
+    return gemm(dy2d, w, M, K, N, trans_b=True, ldb=K, bias=None, res=res, aux=aux, flags=flags, out=out)
+
+
+def linear_bwd_weight(dy2d, x2d, out=None):
+    """dW [N,K] = dy^T x, written as fp32 (directly usable as the master-parameter gradient)."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    if out is None:
+        out = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
+    # A(n, m) = dy[m][n] -> form R ld = N ; B(k, m) = x[m][k] -> form R ld = K ; reduction over m
+    return gemm(dy2d, x2d, N, K, M, trans_a=True, trans_b=True, lda=N, ldb=K, out=out, out_f32=True)
+
+
+_WS = {}
+
+
+def _workspace(key, nfloat, device):
+    """Reusable fp32 scratch (stream-ordered use only)."""
+    t = _WS.get((key, device))
+    if t is None or t.numel() < nfloat:
+        t = torch.empty(int(nfloat), device=device, dtype=torch.float32)
+        _WS[(key, device)] = t
+    return t
+
+
+def colsum(x2d, out=None, accumulate=False):
+    """fp32 [N] = sum over rows of x [M,N] (bias gradients)."""
+    M, N = x2d.shape
+    if out is None:
+        out = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    ws = _workspace("colsum", call("dvlp_colsum_chunks", M) * N, x2d.device)
+    call("dvlp_colsum", dt(x2d), M, N, p(x2d), x2d.stride(0), M, 0, 1, 0, p(out), p(ws), int(accumulate), stream())
+    return out
+
+
+def colsum_grouped(x, M, N, ld, inner, ostride, groups, gstride):
+    out = torch.empty((groups, N), device=x.device, dtype=torch.float32)
+    ws = _workspace("colsum", groups * call("dvlp_colsum_chunks", M) * N, x.device)
+    call("dvlp_colsum", dt(x), M, N, p(x), ld, inner, ostride, groups, gstride, p(out), p(ws), 0, stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, gamma, beta, eps, want_relu=False):
+    M, D = x2d.shape
+    y = torch.empty_like(x2d)
+    yr = torch.empty_like(x2d) if want_relu else None
+    mean = torch.empty(M, device=x2d.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    call("dvlp_layernorm_fwd", dt(x2d), M, D, p(x2d), p(gamma), p(beta), float(eps), p(y), p(yr), p(mean), p(rstd), stream())
+    return y, yr, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None):
+    M, D = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma = torch.empty(D, device=x2d.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace("ln", (call("dvlp_layernorm_bwd_blocks", M) + 1) * 2 * D, x2d.device)
+    call("dvlp_layernorm_bwd", dt(x2d), M, D, p(dy2d), p(x2d), p(gamma), p(mean), p(rstd), p(dres), p(dx), p(dgamma), p(dbeta),
+         p(ws), 0, stream())
+    return dx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------------------------
+HEADS, HEAD_DIM = 12, 64
+SCALE = HEAD_DIM ** -0.5
+
+
+def space_attention_fwd(qkv, addmask, B, F, R):
+    """qkv [B*N, 2304] packed (q | k | v), addmask [B,N] fp32 -> [B*N, 768]."""
+    N = 1 + F * R
+    out = torch.empty((B * N, 768), device=qkv.device, dtype=qkv.dtype)
+    es = qkv.element_size()
+    base = qkv.data_ptr()
+    call("dvlp_attention_fwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(base), ctypes.c_void_p(base + 768 * es),
+         ctypes.c_void_p(base + 1536 * es), 2304, p(addmask), p(out), 768, SCALE, stream())
+    return out
+
+
+def space_attention_bwd(qkv, addmask, dout, B, F, R):
+    N = 1 + F * R
+    dqkv = torch.empty_like(qkv)
+    es = qkv.element_size()
+    b, db = qkv.data_ptr(), dqkv.data_ptr()
+    ws = _workspace("attn", B * HEADS * F * 2 * 64, qkv.device)
+    call("dvlp_attention_bwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(b), ctypes.c_void_p(b + 768 * es),
+         ctypes.c_void_p(b + 1536 * es), 2304, p(addmask), p(dout), 768, ctypes.c_void_p(db), ctypes.c_void_p(db + 768 * es),
+         ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, stream())
+    return dqkv
+
+
+def full_attention_fwd(q, k, v, addmask, B, L):
+    out = torch.empty((B * L, 768), device=q.device, dtype=q.dtype)
+    call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), 768, p(addmask), p(out), 768, SCALE, stream())
+    return out
+
+
+def full_attention_bwd(q, k, v, addmask, dout, B, L):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    call("dvlp_attention_bwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), 768, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
+         768, None, SCALE, stream())
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# prologues
+# ----------------------------------------------------------------------------------------------------------------
+def obj_split(obj, dtype):
+    """obj [B,F,R,2054] fp32 -> feat [M,2048] (compute dtype), box [M,6] fp32."""
+    M = obj.numel() // 2054
+    feat = torch.empty((M, 2048), device=obj.device, dtype=dtype)
+    box = torch.empty((M, 6), device=obj.device, dtype=torch.float32)
+    call("dvlp_obj_split", dt(dtype), M, p(obj), p(feat), p(box), stream())
+    return feat, box
+
+
+def embed_assemble(tok, box, Wp, bp, temporal, cls, pos0, mask01, B, F, R):
+    N = 1 + F * R
+    x = torch.empty((B * N, 768), device=tok.device, dtype=tok.dtype)
+    addmask = torch.empty((B, N), device=tok.device, dtype=torch.float32)
+    call("dvlp_embed_assemble", dt(tok), B, F, R, p(tok), p(box), p(Wp), p(bp), p(temporal), p(cls), p(pos0), p(mask01), p(x),
+         p(addmask), stream())
+    return x, addmask
+
+
+def embed_unassemble(dx, B, F, R):
+    dtok = torch.empty((B * F * R, 768), device=dx.device, dtype=dx.dtype)
+    call("dvlp_embed_unassemble", dt(dx), B, F, R, p(dx), p(dtok), stream())
+    return dtok
+
+
+def box_wgrad(dtok, box):
+    M = dtok.shape[0]
+    out = torch.empty((768, 6), device=dtok.device, dtype=torch.float32)
+    ws = _workspace("boxw", call("dvlp_box_wgrad_chunks", M) * 6 * 768, dtok.device)
+    call("dvlp_box_wgrad", dt(dtok), M, p(dtok), p(box), p(out), p(ws), 0, stream())
+    return out
+
+
+def text_embed_fwd(ids, word, pos, gamma, beta, eps, dtype):
+    B, L = ids.shape
+    e = torch.empty((B * L, 768), device=ids.device, dtype=dtype)
+    y = torch.empty_like(e)
+    mean = torch.empty(B * L, device=ids.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    call("dvlp_text_embed_fwd", dt(dtype), B, L, p(ids), p(word), p(pos), p(gamma), p(beta), float(eps), p(e), p(y), p(mean),
+         p(rstd), stream())
+    return e, y, mean, rstd
+
+
+def text_embed_bwd(ids, de, vocab):
+    dword = torch.zeros((vocab, 768), device=de.device, dtype=torch.float32)
+    call("dvlp_text_embed_bwd", dt(de), de.shape[0], p(ids), p(de), p(dword), stream())
+    return dword
+
+
+def cast(src, dtype, out=None):
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=dtype)
+    call("dvlp_cast", dt(src), dt(dtype), src.numel(), p(src), p(out), stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------------------------
+def xattn_fwd(C, Q, m_img, m_cap, lam, gate, need_bwd):
+    """C [Bi,G,256], Q [Bj,W,256] (compute dtype), additive fp32 masks -> scores fp32 [Bi,Bj], workspace."""
+    Bi, G, d = C.shape
+    Bj, W, _ = Q.shape
+    nbytes = call("dvlp_xattn_workspace_bytes", dt(C), Bi, Bj, G, W, int(need_bwd))
+    ws = torch.empty(int(nbytes), device=C.device, dtype=torch.uint8)
+    scores = torch.empty((Bi, Bj), device=C.device, dtype=torch.float32)
+    call("dvlp_xattn_fwd", dt(C), Bi, Bj, G, W, d, p(C), p(Q), p(m_img), p(m_cap), float(lam), int(gate), p(scores), p(ws),
+         int(need_bwd), stream())
+    return scores, ws
+
+
+def xattn_bwd(C, Q, m_img, m_cap, lam, gate, dscores, ws):
+    Bi, G, d = C.shape
+    Bj, W, _ = Q.shape
+    dC, dQ = torch.empty_like(C), torch.empty_like(Q)
+    call("dvlp_xattn_bwd", dt(C), Bi, Bj, G, W, d, p(C), p(Q), p(m_img), p(m_cap), float(lam), int(gate), p(dscores), p(ws),
+         p(dC), p(dQ), stream())
+    return dC, dQ
+
+
+def global_local_loss(gt, go, xs, temperature, lam, use_global, use_local, stages, sim=None, dsim=None):
+    """Raw call of the fused loss-head kernel.  Returns dict with whichever of sim/dsim/dgt/dgo/dxs/losses were produced."""
+    ref = gt if gt is not None else (xs if xs is not None else sim)
+    B = ref.shape[0]
+    dev = ref.device
+    if sim is None:
+        sim = torch.empty((B, B), device=dev, dtype=torch.float32)
+    if dsim is None:
+        dsim = torch.empty((B, B), device=dev, dtype=torch.float32)
+    dgt = torch.empty_like(gt) if (gt is not None and stages & 4) else None
+    dgo = torch.empty_like(go) if (go is not None and stages & 4) else None
+    dxs = torch.empty_like(xs) if (xs is not None and stages & 2) else None
+    losses = torch.zeros(3, device=dev, dtype=torch.float32)
+    d = dt(gt) if gt is not None else F32
+    call("dvlp_global_local_loss", d, B, 256, p(gt), p(go), p(xs), float(temperature), float(lam), int(use_global), int(use_local),
+         int(stages), p(sim), p(dsim), p(dgt), p(dgo), p(dxs), p(losses), stream())
+    return dict(sim=sim, dsim=dsim, dgt=dgt, dgo=dgo, dxs=dxs, losses=losses)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# region select, optimizer
+# ----------------------------------------------------------------------------------------------------------------
+def region_select(feats, bbox, conf, wh, R, nvalid=None):
+    """feats [B,F,Nraw,2048], bbox [B,F,Nraw,4], conf [B,F,Nraw], wh [B,F,2] (fp32, on device) ->
+    obj [B,F,R,2054] fp32, mask [B,F,R] fp32, order [B,F,R] int32, lens [B,F] int32."""
+    B, F, Nraw, _ = feats.shape
+    dev = feats.device
+    obj = torch.empty((B, F, R, 2054), device=dev, dtype=torch.float32)
+    mask = torch.empty((B, F, R), device=dev, dtype=torch.float32)
+    order = torch.empty((B, F, R), device=dev, dtype=torch.int32)
+    lens = torch.empty((B, F), device=dev, dtype=torch.int32)
+    call("dvlp_region_select", B * F, F, Nraw, R, p(feats), p(bbox), p(conf), p(wh), p(nvalid), p(obj), p(mask), p(order), p(lens),
+         stream())
+    return obj, mask, order, lens
+
+
+def adamw_step(pflat, gflat, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, shadow=None):
+    call("dvlp_adamw_step", pflat.numel(), p(pflat), p(gflat), p(m), p(v), float(lr), float(beta1), float(beta2), float(eps),
+         float(weight_decay), int(step), float(grad_scale), p(shadow), stream())
+
+
+def prof_enable(on: bool):
+    call("dvlp_prof_enable", int(on))
+
+
+def prof_collect():
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    call("dvlp_prof_collect", ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    return ms.value, fl.value, n.value

@@ -1,0 +1,120 @@
+"""DistilBERT encoder with HuggingFace's parameter names (``text_model.*`` keys of the reference state_dict), computed
+by the gfx950 kernels.  The reference gets this tower from ``AutoModel.from_pretrained`` (model/model.py:29); the
+arithmetic is third-party (transformers 4.10.0) -- see SURVEY.md section 8(c).  Dropout is not applied (the parity
+fixtures use dropout 0; train-mode dropout 0.1 of the reference is a documented difference).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .object_transformer import _Affine, _Linear
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, vocab, max_pos, dim):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, dim, padding_idx=0)
+        self.position_embeddings = nn.Embedding(max_pos, dim)
+        self.LayerNorm = _Affine(dim)
+        nn.init.normal_(self.word_embeddings.weight, std=0.02)
+        nn.init.normal_(self.position_embeddings.weight, std=0.02)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.q_lin, self.k_lin, self.v_lin, self.out_lin = (_Linear(dim, dim) for _ in range(4))
+
+
+class _FFN(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.lin1 = _Linear(dim, hidden)
+        self.lin2 = _Linear(hidden, dim)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.attention = _Attention(dim)
+        self.sa_layer_norm = _Affine(dim)
+        self.ffn = _FFN(dim, hidden)
+        self.output_layer_norm = _Affine(dim)
+
+    def forward(self, x, addmask, want_relu=False):
+        a, f = self.attention, self.ffn
+        return Fn.BertLayerFn.apply(x, addmask, a.q_lin.weight, a.q_lin.bias, a.k_lin.weight, a.k_lin.bias, a.v_lin.weight,
+                                    a.v_lin.bias, a.out_lin.weight, a.out_lin.bias, self.sa_layer_norm.weight,
+                                    self.sa_layer_norm.bias, f.lin1.weight, f.lin1.bias, f.lin2.weight, f.lin2.bias,
+                                    self.output_layer_norm.weight, self.output_layer_norm.bias, want_relu)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, n_layers, dim, hidden):
+        super().__init__()
+        self.layer = nn.ModuleList([_Block(dim, hidden) for _ in range(n_layers)])
+
+
+class _Config:
+    def __init__(self, **kw):
+        self.vocab_size = kw.get("vocab_size", 30522)
+        self.max_position_embeddings = kw.get("max_position_embeddings", 512)
+        self.dim = self.hidden_size = kw.get("dim", 768)
+        self.hidden_dim = kw.get("hidden_dim", 3072)
+        self.n_layers = kw.get("n_layers", 6)
+        self.n_heads = kw.get("n_heads", 12)
+
+
+class DistilBertEncoder(nn.Module):
+    def __init__(self, config: _Config | None = None):
+        super().__init__()
+        self.config = config or _Config()
+        c = self.config
+        if c.dim != 768 or c.n_heads != 12 or c.hidden_dim != 3072:
+            raise NotImplementedError("kernels are specialised for distilbert-base (768 / 12 heads / 3072)")
+        self.embeddings = _Embeddings(c.vocab_size, c.max_position_embeddings, c.dim)
+        self.transformer = _Transformer(c.n_layers, c.dim, c.hidden_dim)
+        self.compute_dtype = torch.float32
+
+    @classmethod
+    def from_pretrained(cls, path):
+        """Load ``config.json`` + weights from a HuggingFace directory if it exists; otherwise (no network on this box)
+        build the default distilbert-base-uncased shape with random init."""
+        cfg, sd = {}, None
+        if path and os.path.isdir(path):
+            cj = os.path.join(path, "config.json")
+            if os.path.exists(cj):
+                cfg = json.load(open(cj))
+            st = os.path.join(path, "model.safetensors")
+            pb = os.path.join(path, "pytorch_model.bin")
+            if os.path.exists(st):
+                from safetensors.torch import load_file
+                sd = load_file(st)
+            elif os.path.exists(pb):
+                sd = torch.load(pb, map_location="cpu")
+        m = cls(_Config(**cfg))
+        if sd is not None:
+            sd = {k[len("distilbert."):] if k.startswith("distilbert.") else k: v for k, v in sd.items()}
+            m.load_state_dict(sd, strict=False)
+        return m
+
+    def forward(self, input_ids=None, attention_mask=None, want_relu=False, **_):
+        """Returns last_hidden_state [B,L,768] (and relu of it when ``want_relu``)."""
+        B, L = input_ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        addmask = torch.zeros((B, L), device=input_ids.device, dtype=torch.float32)
+        addmask.masked_fill_(attention_mask == 0, float("-inf"))
+        e = self.embeddings
+        x = Fn.TextEmbedFn.apply(input_ids.contiguous(), e.word_embeddings.weight, e.position_embeddings.weight, e.LayerNorm.weight,
+                                 e.LayerNorm.bias, self.compute_dtype)
+        n = len(self.transformer.layer)
+        xr = None
+        for i, blk in enumerate(self.transformer.layer):
+            x, xr = blk(x, addmask, want_relu and i == n - 1)
+        return (x, xr) if want_relu else x

@@ -1,0 +1,104 @@
+/* demovlp_hip.h -- C ABI of libdemovlp_hip.so: the MI355X (gfx950) kernels behind DemoVLP's cross-modal
+ * forward/backward hot path.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer borrowed from the caller (PyTorch-ROCm allocates; nothing here allocates,
+ *     frees or synchronises except dvlp_prof_collect).  Workspaces are passed in; their sizes come from the
+ *     *_bytes / *_blocks / *_chunks helpers below.
+ *   - `stream` is a hipStream_t; every call is asynchronous on it and re-entrant per stream.
+ *   - `dtype` selects the COMPUTE/STORAGE dtype of activations: DVLP_F32 (exact-fp32 MFMA, the 1e-4 parity path)
+ *     or DVLP_BF16 (bf16 MFMA, fp32 accumulate, the throughput path).  Biases, LayerNorm parameters, statistics,
+ *     masks, losses and optimizer state are always fp32.
+ *   - Return value: 0 on success, negative DVLP_ERR_* otherwise (the Python binding raises).
+ *
+ * The reference (showlab/DemoVLP) has no native code: each entry point below replaces the PyTorch op sequence
+ * cited next to it (paths relative to the reference repo root).
+ */
+#ifndef DEMOVLP_HIP_H
+#define DEMOVLP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DVLP_F32 = 0, DVLP_BF16 = 1 };
+enum { DVLP_OK = 0, DVLP_ERR_DTYPE = -1, DVLP_ERR_SHAPE = -2, DVLP_ERR_LAUNCH = -3, DVLP_ERR_UNSUPPORTED = -4 };
+/* dvlp_gemm epilogue flags */
+enum { DVLP_EPI_GELU = 1, DVLP_EPI_GELU_BWD = 2, DVLP_EPI_RELU_BWD = 4, DVLP_EPI_ACCUM = 8, DVLP_EPI_LEAKY = 16,
+       DVLP_EPI_OUT_F32 = 32 /* C is fp32 whatever the compute dtype (weight gradients) */ };
+
+/* ---- K1 region select: data_loader/WebVid_dataset.py:134-283 (read_all_object_from_disk + object_select_random) ---- */
+int dvlp_region_select(int64_t BF, int64_t F, int64_t Nraw, int64_t R, const float* feats, const float* bbox, const float* conf,
+                       const float* wh, const int* nvalid, float* obj, float* mask, int* order, int* lens, void* stream);
+
+/* ---- GEMM: nn.Linear forward/backward everywhere on the path (model/object_transformer.py:116-122, 155, 194,
+ *      404-408, 451; DistilBERT q/k/v/out/ffn; model/model.py:40-43) and the contractions of model/loss.py:235,267.
+ *      C[M,N] = epi(alpha * op(A) op(B)^T); transX=0: X[r*ld+k], transX=1: X[k*ld+r].                              ---- */
+int dvlp_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+              int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres, void* aux, int64_t ldaux,
+              int flags, float alpha, void* stream);
+int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                      const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                      void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
+                      int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
+/* per-launch HIP-event timing of the GEMM kernels (bench.py roofline figure) */
+int dvlp_prof_enable(int on);
+int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
+
+/* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */
+int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                       void* y_relu, float* mean, float* rstd, void* stream);
+int64_t dvlp_layernorm_bwd_blocks(int64_t M);
+int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace, int accumulate,
+                       void* stream);
+/* bias / table gradients: out[g][n] (+)= sum_m x_g[m][n] */
+int64_t dvlp_colsum_chunks(int64_t M);
+int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
+                int64_t gstride, float* out, float* workspace, int accumulate, void* stream);
+
+/* ---- attention: VarAttention.forward + attn_mask (object_transformer.py:152-196, 91-97) [mode 0] and DistilBERT
+ *      multi-head self-attention [mode 1]                                                                          ---- */
+int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                       const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, void* stream);
+int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                       const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk, void* dv,
+                       int64_t ldd, float* workspace, float scale, void* stream);
+
+/* ---- tower prologues: ObjectTransformer.forward_features (object_transformer.py:400-433); DistilBERT embeddings ---- */
+int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* box, void* stream);
+int dvlp_embed_assemble(int dtype, int64_t B, int64_t F, int64_t R, const void* tok, const float* box, const float* Wp,
+                        const float* bp, const float* temporal, const float* cls, const float* pos0, const float* mask01, void* x,
+                        float* addmask, void* stream);
+int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R, const void* dx, void* dtok, void* stream);
+int64_t dvlp_box_wgrad_chunks(int64_t M);
+int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const float* box, float* dWp, float* workspace, int accumulate,
+                   void* stream);
+int dvlp_text_embed_fwd(int dtype, int64_t B, int64_t L, const int64_t* ids, const float* word, const float* pos,
+                        const float* gamma, const float* beta, float eps, void* e_out, void* y, float* mean, float* rstd,
+                        void* stream);
+int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, const void* de, float* dword, void* stream);
+int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream);
+
+/* ---- local loss: xattn_score_fast / func_attention_fast / focal_equal / cosine_similarity (model/loss.py:209-330) ---- */
+int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd);
+int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
+                   const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd, void* stream);
+int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
+                   const float* mimg, const float* mcap, float lam, int gate, const float* dscores, void* workspace, void* dC,
+                   void* dQ, void* stream);
+
+/* ---- loss heads: sim_matrix (model/model.py:582-590) + NormSoftmaxLoss (model/loss.py:126-138) + RWALoss tail
+ *      (model/loss.py:105-116) + GlobalLocalLoss sum (:29-45); forward and analytic gradients in one launch        ---- */
+int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,
+                           float lam, int use_global, int use_local, int stages, float* sim, float* dsim, void* dgt, void* dgo,
+                           float* dxs, float* losses, void* stream);
+
+/* ---- optimizer: transformers.AdamW as constructed at train_dist_multi.py:64 ---- */
+int dvlp_adamw_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, float grad_scale, void* bf16_shadow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

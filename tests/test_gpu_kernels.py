@@ -1,0 +1,286 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the CPU oracle / a plain torch fp32 statement of
+the same op, on seeded inputs.  fp32 path: 1e-4 (relative to max(1,|ref|)); bf16 path: stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demovlp_amd import ops, synthetic as syn  # noqa: E402
+from oracle import restatement as orc  # noqa: E402
+
+DEV = "cuda"
+F32_TOL = 1e-4
+BF16_TOL = 3e-2
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+def tol(dtype):
+    return F32_TOL if dtype == torch.float32 else BF16_TOL
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(578, 768, 768), (300, 200, 104), (128, 128, 64), (1, 256, 768), (130, 2304, 768)])
+def test_gemm_forward_forms(dtype, M, N, K):
+    a, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1)
+    ref = a.float() @ w.float().t()
+    y = ops.gemm(a, w, M, N, K)
+    assert rel(y, ref) < tol(dtype) * math.sqrt(K) / 8
+    # dx = dy W : A form K, B form R
+    dy = rnd(M, N, dtype=dtype, seed=2)
+    dx = ops.linear_bwd_input(dy, w)
+    assert rel(dx, dy.float() @ w.float()) < tol(dtype) * math.sqrt(N) / 8
+    # dW = dy^T x : A form R, B form R, fp32 output
+    dw = ops.linear_bwd_weight(dy, a)
+    assert dw.dtype == torch.float32
+    assert rel(dw, dy.float().t() @ a.float()) < tol(dtype) * math.sqrt(M) / 4
+    # (R, K): A stored [K][M], B stored [N][K]
+    if dtype == torch.float32 or M % 8 == 0:      # bf16 operands need 16-byte aligned rows
+        at = a.t().contiguous()
+        y2 = ops.gemm(at, w, M, N, K, trans_a=True, lda=M)
+        assert rel(y2, ref) < tol(dtype) * math.sqrt(K) / 8
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype):
+    M, N, K = 260, 384, 256
+    a, w = rnd(M, K, dtype=dtype, scale=0.5), rnd(N, K, dtype=dtype, seed=1, scale=0.2)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, dtype=dtype, seed=4)
+    lin = a.float() @ w.float().t() + bias
+    t = tol(dtype) * 2
+    assert rel(ops.linear_fwd(a, w, bias), lin) < t
+    assert rel(ops.linear_fwd(a, w, bias, res=res), lin + res.float()) < t
+    pre = torch.empty(M, N, device=DEV, dtype=dtype)
+    act = ops.linear_fwd(a, w, bias, gelu_aux=pre)
+    assert rel(pre, lin) < t and rel(act, orc.gelu_erf(lin)) < t
+    # gelu backward epilogue
+    dy = rnd(M, N, dtype=dtype, seed=5)
+    w2 = rnd(N, K, dtype=dtype, seed=6, scale=0.2)      # treat as [N_out=N][K_in=K]; dx = dy W2 -> [M,K]
+    prek = rnd(M, K, dtype=dtype, seed=7)
+    x = prek.float().clone().requires_grad_(True)
+    (orc.gelu_erf(x) * (dy.float() @ w2.float())).sum().backward()
+    got = ops.linear_bwd_input(dy, w2, gelu_pre=prek)
+    assert rel(got, x.grad) < t
+    got = ops.linear_bwd_input(dy, w2, relu_pre=prek)
+    assert rel(got, (dy.float() @ w2.float()) * (prek.float() > 0)) < t
+    # accumulate + residual
+    base = rnd(M, K, dtype=dtype, seed=8)
+    out = base.clone()
+    ops.linear_bwd_input(dy, w2, out=out, accumulate=True)
+    assert rel(out, base.float() + dy.float() @ w2.float()) < t
+    # leaky + batched
+    Bn = 3
+    A3, B3 = rnd(Bn, 64, 256, dtype=dtype, scale=0.3), rnd(Bn, 72, 256, dtype=dtype, seed=9, scale=0.3)
+    C3 = torch.empty(Bn, 64, 72, device=DEV, dtype=dtype)
+    ops.call("dvlp_gemm_batched", ops.dt(dtype), 0, 0, 64, 72, 256, ops.p(A3), 256, ops.p(B3), 256, ops.p(C3), 72, None, None, 0, None, 0,
+             ops.EPI_LEAKY, 1.0, Bn, 64 * 256, 72 * 256, 64 * 72, 0, 0, ops.stream())
+    ref = torch.nn.functional.leaky_relu(A3.float() @ B3.float().transpose(1, 2), 0.1)
+    assert rel(C3, ref) < t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [5, 578, 1301])
+def test_layernorm(dtype, M):
+    D = 768
+    x = rnd(M, D, dtype=dtype, scale=2.0)
+    g, b = 1 + 0.1 * rnd(D, seed=1), 0.1 * rnd(D, seed=2)
+    for eps in (1e-6, 1e-12):
+        y, yr, mean, rstd = ops.layernorm_fwd(x, g, b, eps, want_relu=True)
+        xr = x.float().clone().requires_grad_(True)
+        gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, eps)
+        assert rel(y, ref) < tol(dtype)
+        assert rel(yr, ref.relu()) < tol(dtype)
+        dy = rnd(M, D, dtype=dtype, seed=3)
+        dres = rnd(M, D, dtype=dtype, seed=4)
+        ref.backward(dy.float())
+        dx, dg, db = ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)
+        assert rel(dx, xr.grad + dres.float()) < tol(dtype) * 2
+        assert rel(dg, gr.grad) < tol(dtype) * 4 and rel(db, br.grad) < tol(dtype) * 4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum(dtype):
+    x = rnd(1000, 3072, dtype=dtype)
+    assert rel(ops.colsum(x), x.float().sum(0)) < tol(dtype)
+    B, F, R = 3, 4, 5
+    t = rnd(B * F * R, 768, dtype=dtype, seed=1)
+    got = ops.colsum_grouped(t, B * R, 768, 768, R, F * R * 768, F, R * 768)
+    assert rel(got, t.float().reshape(B, F, R, 768).sum((0, 2))) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,F,R", [(2, 8, 36), (3, 1, 30), (1, 32, 36), (2, 8, 30)])
+def test_space_attention(dtype, B, F, R):
+    N = 1 + F * R
+    qkv = rnd(B * N, 2304, dtype=dtype, scale=1.5)
+    mask01 = (torch.rand(B, N - 1, generator=torch.Generator().manual_seed(1)) > 0.2).float()
+    addmask = torch.cat([torch.zeros(B, 1), (mask01 - 1) * 100], 1).to(DEV)
+    q = qkv.float().reshape(B, N, 2304).clone().requires_grad_(True)
+    ref = orc.space_attention(q, addmask, F, R)
+    out = ops.space_attention_fwd(qkv, addmask, B, F, R)
+    assert rel(out, ref.reshape(B * N, 768)) < tol(dtype)
+    dout = rnd(B * N, 768, dtype=dtype, seed=2)
+    ref.backward(dout.float().reshape(B, N, 768))
+    dqkv = ops.space_attention_bwd(qkv, addmask, dout, B, F, R)
+    assert rel(dqkv, q.grad.reshape(B * N, 2304)) < tol(dtype) * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L", [(2, 100), (3, 37), (1, 128)])
+def test_full_attention(dtype, B, L):
+    q, k, v = (rnd(B * L, 768, dtype=dtype, seed=s, scale=1.5) for s in range(3))
+    att = torch.ones(B, L, dtype=torch.long)
+    att[0, L // 3:] = 0
+    addmask = torch.zeros(B, L).masked_fill(att == 0, float("-inf")).to(DEV)
+    qq, kk, vv = (t.float().reshape(B, L, 768).clone().requires_grad_(True) for t in (q, k, v))
+    ref = orc.text_attention(qq, kk, vv, att.to(DEV))
+    out = ops.full_attention_fwd(q, k, v, addmask, B, L)
+    assert rel(out, ref.reshape(B * L, 768)) < tol(dtype)
+    dout = rnd(B * L, 768, dtype=dtype, seed=5)
+    ref.backward(dout.float().reshape(B, L, 768))
+    dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, dout, B, L)
+    for got, r in ((dq, qq.grad), (dk, kk.grad), (dv, vv.grad)):
+        assert rel(got, r.reshape(B * L, 768)) < tol(dtype) * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_object_prologue_pieces(dtype):
+    B, F, R = 2, 3, 5
+    obj = rnd(B, F, R, 2054).abs()
+    feat, box = ops.obj_split(obj, dtype)
+    assert rel(feat, obj.reshape(-1, 2054)[:, :2048]) < tol(dtype) and torch.equal(box, obj.reshape(-1, 2054)[:, 2048:])
+    tok = rnd(B * F * R, 768, dtype=dtype, seed=1)
+    Wp, bp, temporal, cls, pos0 = rnd(768, 6, seed=2), rnd(768, seed=3), rnd(F, 768, seed=4), rnd(768, seed=5), rnd(768, seed=6)
+    mask01 = (torch.rand(B, F, R) > 0.3).float().to(DEV)
+    x, addmask = ops.embed_assemble(tok, box, Wp, bp, temporal, cls, pos0, mask01, B, F, R)
+    ref = tok.float() + (box @ Wp.t() + bp)
+    ref = ref.reshape(B, F * R, 768) + temporal.repeat_interleave(R, 0)[None]
+    ref = torch.cat([(cls + pos0)[None, None].expand(B, 1, 768), ref], 1)
+    assert rel(x, ref.reshape(-1, 768)) < tol(dtype)
+    refm = torch.cat([torch.zeros(B, 1, device=DEV), (mask01.reshape(B, -1) - 1) * 100], 1)
+    assert torch.equal(addmask, refm)
+    dx = rnd(B * (1 + F * R), 768, dtype=dtype, seed=7)
+    dtok = ops.embed_unassemble(dx, B, F, R)
+    assert torch.equal(dtok, dx.reshape(B, 1 + F * R, 768)[:, 1:].reshape(-1, 768))
+    assert rel(ops.box_wgrad(dtok, box), dtok.float().t() @ box) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_text_embed(dtype):
+    B, L, V = 3, 20, 500
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(0))
+    ids[:, -3:] = 0
+    ids = ids.to(DEV)
+    word, pos = rnd(V, 768, scale=0.5), rnd(512, 768, seed=1, scale=0.5)
+    g, b = 1 + 0.1 * rnd(768, seed=2), 0.1 * rnd(768, seed=3)
+    e, y, mean, rstd = ops.text_embed_fwd(ids, word, pos, g, b, 1e-12, dtype)
+    ref_e = word[ids] + pos[:L][None]
+    assert rel(e, ref_e.reshape(-1, 768)) < tol(dtype)
+    assert rel(y, torch.nn.functional.layer_norm(ref_e, (768,), g, b, 1e-12).reshape(-1, 768)) < tol(dtype)
+    de = rnd(B * L, 768, dtype=dtype, seed=4)
+    dword = ops.text_embed_bwd(ids, de, V)
+    ref = torch.zeros(V, 768, device=DEV).index_add_(0, ids.reshape(-1), de.float())
+    ref[0] = 0
+    assert rel(dword, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Bi,Bj,G,W,gate", [(2, 2, 288, 99, True), (3, 4, 240, 99, True), (2, 3, 30, 99, True), (3, 3, 64, 17, False)])
+def test_xattn(dtype, Bi, Bj, G, W, gate):
+    rng = np.random.default_rng(7 + G)
+    im = rng.standard_normal((Bi, G, 256), dtype=np.float32)
+    cap = rng.standard_normal((Bj, W, 256), dtype=np.float32)
+    n = min(G, W)
+    for b in range(min(Bi, Bj)):
+        cap[b, :n, :64] += 0.5 * im[b, :n, :64]
+    m_img = np.zeros((Bi, G), np.float32); m_img[-1, G - 4:] = -100
+    m_cap = np.full((Bj, W), -100.0, np.float32)
+    for b in range(Bj):
+        m_cap[b, : 5 + 3 * b] = 0
+    C = torch.from_numpy(im).to(DEV).to(dtype); Q = torch.from_numpy(cap).to(DEV).to(dtype)
+    mi, mc = torch.from_numpy(m_img).to(DEV), torch.from_numpy(m_cap).to(DEV)
+    Cr, Qr = C.float().cpu().requires_grad_(True), Q.float().cpu().requires_grad_(True)
+    ref = orc.xattn_scores_batched(Cr, Qr, mi.cpu(), mc.cpu(), 20.0, gate)
+    scores, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, gate, True)
+    t = F32_TOL if dtype == torch.float32 else 2e-2
+    assert rel(scores, ref) < t
+    dsc = torch.from_numpy(rng.standard_normal((Bi, Bj)).astype(np.float32))
+    ref.backward(dsc)
+    dC, dQ = ops.xattn_bwd(C, Q, mi, mc, 20.0, gate, dsc.to(DEV), ws)
+    tg = 2e-3 if dtype == torch.float32 else 1e-1
+    assert float((dC.float().cpu() - Cr.grad).abs().max()) < tg * float(Cr.grad.abs().max())
+    assert float((dQ.float().cpu() - Qr.grad).abs().max()) < tg * float(Qr.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B", [2, 16, 64])
+def test_loss_heads(dtype, B):
+    a, b = rnd(B, 256, dtype=dtype), rnd(B, 256, dtype=dtype, seed=1)
+    b = (b.float() + 0.5 * a.float()).to(dtype)
+    xs = (torch.rand(B, B, generator=torch.Generator().manual_seed(2)) * 0.3 + 0.4 + 0.2 * torch.eye(B)).to(DEV)
+    ar, br, xr = a.float().clone().requires_grad_(True), b.float().clone().requires_grad_(True), xs.clone().requires_grad_(True)
+    sim = orc.sim_matrix(ar, br)
+    g, l = orc.norm_softmax_loss(sim), orc.rwa_loss(xr)
+    (g + l).backward()
+    r = ops.global_local_loss(a, b, xs, 0.05, 20.0, 1, 1, 7)
+    assert rel(r["sim"], sim) < 1e-5
+    assert abs(r["losses"][1].item() - g.item()) < 1e-4 * max(1, abs(g.item()))
+    assert abs(r["losses"][2].item() - l.item()) < 1e-4 * max(1, abs(l.item()))
+    assert abs(r["losses"][0].item() - (g + l).item()) < 2e-4 * max(1, abs((g + l).item()))
+    t = 2e-4 if dtype == torch.float32 else 2e-2
+    assert float((r["dgt"].float() - ar.grad).abs().max()) < t * float(ar.grad.abs().max()) + 1e-7
+    assert float((r["dgo"].float() - br.grad).abs().max()) < t * float(br.grad.abs().max()) + 1e-7
+    assert float((r["dxs"] - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("sample,R", [(0, 36), (1, 36), (2, 36), (3, 30), (2, 30), (1, 30)])
+def test_region_select_bit_exact(sample, R):
+    from helpers import n_raw_for, oracle_clip, load_golden
+    F = 3
+    nraw = n_raw_for(sample)
+    frames = [syn.make_frame(sample, f, nraw) for f in range(F)]
+    feats = torch.from_numpy(np.stack([fr["x"] for fr in frames])[None]).to(DEV)
+    bbox = torch.from_numpy(np.stack([fr["bbox"] for fr in frames])[None]).to(DEV)
+    conf = torch.from_numpy(np.stack([fr["objects_conf"] for fr in frames])[None]).to(DEV)
+    wh = torch.tensor([[[640.0, 360.0]] * F], device=DEV)
+    obj, mask, order, lens = ops.region_select(feats, bbox, conf, wh, R)
+    ref_obj, ref_mask, ref_lens, ref_orders = oracle_clip(sample, F, R)
+    assert lens[0].tolist() == ref_lens
+    for f in range(F):
+        assert order[0, f, : ref_lens[f]].tolist() == ref_orders[f].tolist()
+        assert (order[0, f, ref_lens[f]:] == -1).all()
+    assert np.array_equal(obj[0].cpu().numpy(), ref_obj)              # bit-exact features AND fp32 geometry
+    assert np.array_equal(mask[0].cpu().numpy().astype(np.float64), ref_mask)
+    g = load_golden("g1_region_select.npz")                              # and straight against the reference's output
+    assert np.array_equal(g[f"s{sample}_R{R}_geo"], obj[0, ..., 2048:].cpu().numpy())
+    assert np.array_equal(g[f"s{sample}_R{R}_order"][:, :].clip(min=-1), order[0].cpu().numpy())
+
+
+def test_adamw_matches_oracle():
+    n = 10007
+    p0, g = rnd(n), rnd(n, seed=1, scale=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    pr, mr, vr = p0.clone().cpu(), torch.zeros(n), torch.zeros(n)
+    for step in range(1, 6):
+        ops.adamw_step(p, g * step, m, v, 1e-3, 0.9, 0.999, 1e-6, 0.01, step, 1.0, shadow)
+        orc.hf_adamw_step(pr, (g * step).cpu(), mr, vr, step, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    assert rel(p, pr) < 1e-6 and rel(m, mr) < 1e-6 and rel(v, vr) < 1e-6
+    assert torch.equal(shadow, p.to(torch.bfloat16))
