@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Throughput of the DemoVLP cross-modal hot path on MI355X: video-text pairs/s, fwd + bwd + optimizer step.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = trainer/trainer_dist.py:144-171 on one synthetic batch already resident in HBM: ObjectRelation forward (region
+transformer + DistilBERT), sim_matrix, GlobalLocalLoss (NT-Xent-style global + region<->word local loss, focal gate
+'equal'), backward, fused HF-AdamW.  Workload = BASELINE.json configs[1]: 8 frames x 36 regions x 2048-d synthetic region
+features + random captions, per-GPU batch 64, bf16 MFMA / fp32 accumulate, random-init (closed-form) weights.
+N > 1: pure data parallel (weak scaling), gradient all-reduce over RCCL overlapped with backward; per-rank local
+negatives exactly as the reference trains.
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the MFMA GEMM family): algorithmic flops of
+all its launches / their summed duration, measured with HIP events on the launch stream inside the timed region.
+``cpu_baseline`` times the CPU oracle (oracle/restatement.py, a port proven equal to the reference by tests/golden) on
+the host cores, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def flops_per_pair(B, F, R, W=99, Lt=100):
+    """Algorithmic fwd+bwd FLOPs per video-text pair; bwd = 2 x fwd."""
+    N = 1 + F * R
+    enc = 2 * F * R * 2054 * 768 + 12 * (2 * N * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + 4 * F * R * (R + 1) * 768 + 4 * N * 768) \
+        + 2 * N * 768 * 256
+    txt = 6 * (2 * Lt * (4 * 768 * 768 + 2 * 768 * 3072) + 4 * Lt * Lt * 768) + 2 * Lt * 768 * 256
+    loc = B * 3 * 2 * F * R * W * 256
+    return 3.0 * (enc + txt + loc), 3.0 * enc
+
+
+def cpu_baseline(F, R, budget_s=25.0):
+    """The oracle's full train step (fwd + loss + bwd) on the host cores at B=2 (BASELINE.json configs[0])."""
+    from demovlp_amd import synthetic as syn
+    from oracle import restatement as orc
+    B = 2
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=True)
+    obj, mask = syn.fast_region_batch(B, F, R)
+    ids, att = syn.caption_batch(B)
+    args = (torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask))
+    orc.train_step(p, *args)                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for v in p.values():
+            v.grad = None
+        orc.train_step(p, *args)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 8:
+            break
+    return dict(value=round(B * n / dt, 3), unit="pairs/s", cores=cores, kind="port",
+                sample=f"{n} steps of oracle.train_step (fwd+loss+bwd, fp32, torch CPU) at B={B}, F={F}, R={R}, after 1 warm-up")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from demovlp_amd import ops, synthetic as syn
+    from demovlp_amd.loss import GlobalLocalLoss
+    from demovlp_amd.model import ObjectRelation
+    from demovlp_amd.trainer import FusedAdamW, GradReducer, ParamArena, train_step
+
+    B, F, R = a.batch, a.frames, a.regions
+    cdt = "bfloat16" if a.dtype == "bf16" else "float32"
+    model = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
+                           {"model": "", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=cdt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R).items()})
+    model.to(dev)
+    arena = ParamArena(model, bf16_shadow=(a.dtype == "bf16"))
+    opt = FusedAdamW(arena, lr=1e-5)
+    reducer = GradReducer(arena, bucket_mb=64.0) if world > 1 else None
+    loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+
+    obj, mask = syn.fast_region_batch(B, F, R, seed=7 + rank)
+    ids, att = syn.caption_batch(B, first_sample=rank * B)
+    data = {"text": {"input_ids": torch.from_numpy(ids).to(dev), "attention_mask": torch.from_numpy(att).to(dev)},
+            "object": torch.from_numpy(obj).to(dev), "object_mask": torch.from_numpy(mask).to(dev)}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(a.warmup):
+        loss, _, _ = train_step(model, loss_fn, opt, data, reducer)
+    sync()
+    if not a.no_kernel_timing:
+        ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _, _ = train_step(model, loss_fn, opt, data, reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    gemm_ms, gemm_flops, gemm_n = ops.prof_collect() if not a.no_kernel_timing else (0.0, 0.0, 0)
+    final_loss = float(loss.item())
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        pairs = B * world * a.steps
+        value = pairs / elapsed
+        fpp, fpp_obj = flops_per_pair(B, F, R)
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "video-text pairs/sec/node (fwd+bwd+optimizer step) on 8-frame x 36-region synthetic",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "configs/pt/o2t-cl-local-select-loss-cc.json arch+loss, F=%d frames x R=%d regions x 2048-d synthetic "
+                                   "region features + random 100-token captions, per-GPU batch %d" % (F, R, B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "optimizer": "fused HF-AdamW",
+                       "final_loss": round(final_loss, 4)},
+            "step_model_tflops": round(value * fpp / 1e12, 2),
+            "step_frac_of_mfma_peak": round(value * fpp / 1e12 / (peak * world), 4),
+        }
+        if gemm_n:
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "traffic": None, "kernel": "gemm_%s_kernel (all forms)" % ("bf16" if a.dtype == "bf16" else "f32"),
+                               "launches_per_step": gemm_n // a.steps, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
+                               "gemm_share_of_step": round(gemm_ms * 1e-3 / elapsed, 3)}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(F, R)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
