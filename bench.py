@@ -42,18 +42,36 @@ def flops_per_pair(B, F, R, W=99, Lt=100):
     return 3.0 * (enc + txt + loc), 3.0 * enc
 
 
-def cpu_baseline(F, R, budget_s=25.0):
+def usable_cores(cap=64):
+    """Cores this process may really use: affinity mask, clipped by the cgroup CPU quota (a 256-thread pool inside an
+    8-core quota runs two orders of magnitude slower than 8 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(F, R, budget_s=20.0):
     """The oracle's full train step (fwd + loss + bwd) on the host cores at B=2 (BASELINE.json configs[0])."""
     from demovlp_amd import synthetic as syn
     from oracle import restatement as orc
     B = 2
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=True)
     obj, mask = syn.fast_region_batch(B, F, R)
     ids, att = syn.caption_batch(B)
     args = (torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask))
+    tw = time.perf_counter()
     orc.train_step(p, *args)                                   # warm-up
+    tw = time.perf_counter() - tw
+    if tw > budget_s:                                          # a single step already exhausts the budget: report it
+        return dict(value=round(B / tw, 4), unit="pairs/s", cores=cores, kind="port",
+                    sample=f"1 step (the warm-up itself, {tw:.1f} s) of oracle.train_step at B={B}, F={F}, R={R}")
     n, t0 = 0, time.perf_counter()
     while True:
         for v in p.values():

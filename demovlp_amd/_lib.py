@@ -77,5 +77,10 @@ def call(name, *args):
     if name in _RET64:
         return rc
     if rc != 0:
-        raise DemoVLPHipError(f"{name} failed: {ERRORS.get(rc, rc)}")
+        detail = ""
+        if rc == -3:
+            f = load().dvlp_last_error_string
+            f.restype = ctypes.c_char_p
+            detail = f" ({f().decode()})"
+        raise DemoVLPHipError(f"{name} failed: {ERRORS.get(rc, rc)}{detail}")
     return rc

@@ -281,6 +281,7 @@ static int attn_check(const AttnArgs& a) {
 
 extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
                                   const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, void* stream) {
+    dvlp_clear_status();
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.out = out; a.ldo = ldo;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
@@ -304,6 +305,7 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
 extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
                                   const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk,
                                   void* dv, int64_t ldd, float* workspace, float scale, void* stream) {
+    dvlp_clear_status();
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.dout = dout; a.ldo = ldo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd;
     a.ws = workspace;

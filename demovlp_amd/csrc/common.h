@@ -41,5 +41,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
-static inline int dvlp_launch_status() { return hipGetLastError() == hipSuccess ? DVLP_OK : DVLP_ERR_LAUNCH; }
+// hipGetLastError() is sticky per thread and also reports errors left behind by OTHER libraries' benign failed calls
+// (e.g. a failed attribute query inside the framework), so judge a launch by the error state it changes: clear before
+// launching (dvlp_clear_status) and read after (dvlp_launch_status).
+extern int g_dvlp_last_hip_error;      // defined in gemm.hip; read through dvlp_last_error_string()
+static inline void dvlp_clear_status() { (void)hipGetLastError(); }
+static inline int dvlp_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return DVLP_OK;
+    g_dvlp_last_hip_error = (int)e;
+    return DVLP_ERR_LAUNCH;
+}
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -143,6 +143,7 @@ __global__ void cast_kernel(int64_t n, const S* __restrict__ src, D* __restrict_
 }
 
 extern "C" int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* box, void* stream) {
+    dvlp_clear_status();
     if (M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DVLP_F32) hipLaunchKernelGGL(obj_split_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, M, obj, (float*)feat, box);
@@ -154,6 +155,7 @@ extern "C" int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat
 extern "C" int dvlp_embed_assemble(int dtype, int64_t B, int64_t F, int64_t R, const void* tok, const float* box, const float* Wp,
                                    const float* bp, const float* temporal, const float* cls, const float* pos0, const float* mask01,
                                    void* x, float* addmask, void* stream) {
+    dvlp_clear_status();
     if (B <= 0 || F <= 0 || R <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(B * (1 + F * R))), block(256);
@@ -164,6 +166,7 @@ extern "C" int dvlp_embed_assemble(int dtype, int64_t B, int64_t F, int64_t R, c
 }
 
 extern "C" int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R, const void* dx, void* dtok, void* stream) {
+    dvlp_clear_status();
     if (B <= 0 || F <= 0 || R <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(B * F * R)), block(256);
@@ -176,6 +179,7 @@ extern "C" int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R,
 // workspace: fp32 [dvlp_box_wgrad_chunks(M) * 6 * 768]
 extern "C" int64_t dvlp_box_wgrad_chunks(int64_t M) { const int64_t c = cdiv(M, 64); return c < 256 ? c : 256; }
 extern "C" int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const float* box, float* dWp, float* workspace, int accumulate, void* stream) {
+    dvlp_clear_status();
     if (M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = dvlp_box_wgrad_chunks(M), rows_per = cdiv(M, P);
@@ -190,6 +194,7 @@ extern "C" int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const floa
 extern "C" int dvlp_text_embed_fwd(int dtype, int64_t B, int64_t L, const int64_t* ids, const float* word, const float* pos,
                                    const float* gamma, const float* beta, float eps, void* e_out, void* y, float* mean, float* rstd,
                                    void* stream) {
+    dvlp_clear_status();
     if (B <= 0 || L <= 0 || L > 512) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t M = B * L;
@@ -202,6 +207,7 @@ extern "C" int dvlp_text_embed_fwd(int dtype, int64_t B, int64_t L, const int64_
 
 // dword must be zeroed by the caller (dense [V,768] gradient, as nn.Embedding produces)
 extern "C" int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, const void* de, float* dword, void* stream) {
+    dvlp_clear_status();
     if (M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DVLP_F32) hipLaunchKernelGGL(text_embed_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, M, ids, (const float*)de, dword);
@@ -211,6 +217,7 @@ extern "C" int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, con
 }
 
 extern "C" int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
+    dvlp_clear_status();
     if (n <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     int64_t blocks = cdiv(n, 1024); if (blocks > 4096) blocks = 4096;

@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 // ------------------------------------------------------------------------------------------------------------------
 // optional per-launch HIP-event timing (bench.py's roofline figure is measured with these, on the launch stream)
 // ------------------------------------------------------------------------------------------------------------------
+int g_dvlp_last_hip_error = 0;
+extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipError_t)g_dvlp_last_hip_error); }
+
 struct ProfRec { hipEvent_t a, b; double flops; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
@@ -318,6 +321,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
                                  const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
                                  void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
                                  int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream) {
+    dvlp_clear_status();
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return DVLP_ERR_SHAPE;
     if ((flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD)) && !aux) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;

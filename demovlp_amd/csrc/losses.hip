@@ -153,6 +153,7 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
 extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,
                                       float lam, int use_global, int use_local, int stages, float* sim, float* dsim, void* dgt, void* dgo,
                                       float* dxs, float* losses, void* stream) {
+    dvlp_clear_status();
     if (d != LD_ || B <= 0 || B > 2048) return DVLP_ERR_SHAPE;
     if (use_local && !xs) return DVLP_ERR_SHAPE;
     LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages};

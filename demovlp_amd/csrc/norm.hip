@@ -145,6 +145,7 @@ __global__ void reduce_groups_kernel(int64_t P, int64_t C, const float* __restri
 
 extern "C" int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps,
                                   void* y, void* y_relu, float* mean, float* rstd, void* stream) {
+    dvlp_clear_status();
     if (D % 256 || D > 256 * LN_MAXC || M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(M, 4)), block(256);
@@ -160,6 +161,7 @@ extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv
 extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace,
                                   int accumulate, void* stream) {
+    dvlp_clear_status();
     if (D % 256 || D > 256 * LN_MAXC || M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = dvlp_layernorm_bwd_blocks(M);
@@ -182,6 +184,7 @@ extern "C" int64_t dvlp_colsum_chunks(int64_t M) { const int64_t c = cdiv(M, 64)
 
 extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
                            int64_t gstride, float* out, float* workspace, int accumulate, void* stream) {
+    dvlp_clear_status();
     if (M <= 0 || N <= 0 || groups <= 0 || inner <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = dvlp_colsum_chunks(M), rows_per = cdiv(M, P);

@@ -37,6 +37,7 @@ __global__ void adamw_kernel(int64_t n, float* __restrict__ p, const float* __re
 // step is 1-based.  grad_scale lets the caller fold a gradient average (1/world_size) into the update.
 extern "C" int dvlp_adamw_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int64_t step, float grad_scale, void* bf16_shadow, void* stream) {
+    dvlp_clear_status();
     if (n <= 0 || step <= 0) return DVLP_ERR_SHAPE;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void region_select_kernel(int F, int Nraw, int
 // -> obj [B*F][R][2054], mask [B*F][R] (1/0), order [B*F][R] (source index, -1 = pad), lens [B*F]
 extern "C" int dvlp_region_select(int64_t BF, int64_t F, int64_t Nraw, int64_t R, const float* feats, const float* bbox, const float* conf,
                                   const float* wh, const int* nvalid, float* obj, float* mask, int* order, int* lens, void* stream) {
+    dvlp_clear_status();
     if (BF <= 0 || Nraw <= 0 || Nraw > SEL_MAXN || R <= 0) return DVLP_ERR_SHAPE;
     hipLaunchKernelGGL(region_select_kernel, dim3((unsigned)BF), dim3(256), 0, (hipStream_t)stream, (int)F, (int)Nraw, (int)R, feats, bbox,
                        conf, wh, nvalid, obj, mask, order, lens);

@@ -404,6 +404,7 @@ static size_t pair_lds(int64_t G, int64_t W, int bwd) {
 extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                               const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd,
                               void* stream) {
+    dvlp_clear_status();
     if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAXK || W > 64 * XMAXK) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
     if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;      // long-video (G > ~380) tiling: not in round 1
@@ -454,6 +455,7 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
 extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                               const float* mimg, const float* mcap, float lam, int gate, const float* dscores, void* workspace,
                               void* dC, void* dQ, void* stream) {
+    dvlp_clear_status();
     if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAXK || W > 64 * XMAXK) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
     if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;
