@@ -54,6 +54,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; import it FIRST so this library binds to the same HIP runtime
+    # (loading /opt/rocm's copy first gives the process two runtimes and ours then sees "no ROCm-capable device").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DemoVLPHipError(f"{LIB_PATH} is missing: build it with `python -m demovlp_amd.build` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback.")

@@ -31,6 +31,7 @@ struct AttnArgs {
     float* ws;                 // bwd space mode: [B, H, F, 2, 64] partial dK/dV of the CLS key
     int B, N, H, F, R, mode;
     float scale;
+    int seg_begin;             // first segment index served by blockIdx.x = 0 (CLS-only launches start at nseg)
 };
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
@@ -66,7 +67,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int seg = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int seg = blockIdx.x + a.seg_begin, h = blockIdx.y, b = blockIdx.z;
     const int nseg = a.mode == 0 ? a.F : 1;
     const int64_t brow0 = (int64_t)b * a.N;
     const T* q = (const T*)a.q; const T* k = (const T*)a.k; const T* v = (const T*)a.v; T* out = (T*)a.out;
@@ -271,6 +272,352 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     if (wid == 0) dq[brow0 * a.ldd + h * HD + lane] = from_f<T>((red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) * a.scale);
 }
 
+
+// ==================================================================================================================
+// bf16 MFMA path (v_mfma_f32_16x16x32_bf16).  One WAVE owns one (batch, head, frame) [space] or one (batch, head,
+// query-tile group) [full]; tiles are 16 x 16 with the 64-wide head dim as two k-steps.
+//
+// Trick that keeps P in registers between the two products: compute S^T = K Q^T (A = K rows, B = Q rows, both plain
+// 16-byte global row reads), so a lane holds S^T[key = 16 kt + 4 (lane>>4) + r][q = lane&15]: its softmax column is
+// (lane&15) and the row reductions are two xor-shuffles (16, 32).  The same registers, converted to bf16, ARE the A
+// operand of O = P V if the contraction index of each 32-wide k-step is permuted as
+//     k = 8 g + j  <->  key = 16 kt_(j>>2) + 4 g + (j&3)        (g = lane>>4)
+// and the B operand (V) is read from a row-major LDS tile with the transposing read, whose 4-row blocks are exactly
+// rows 16 kt + 4 g + {0..3}.  Backward uses the same rule in both orientations (S^T for dQ, S for dK/dV).
+// ==================================================================================================================
+constexpr int VLD = 72;    // LDS tile row stride in elements (144 B: 16-byte aligned rows, spreads the tr-read banks)
+
+struct Seg {
+    int mode, R, L, f, qbase;
+    __device__ __forceinline__ int tok_q(int i) const {
+        if (mode == 0) return i < R ? 1 + f * R + i : -1;
+        const int t = qbase + i;
+        return t < L ? t : -1;
+    }
+    __device__ __forceinline__ int tok_k(int j) const {
+        if (mode == 0) return j == 0 ? 0 : (j <= R ? f * R + j : -1);
+        return j < L ? j : -1;
+    }
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }
+
+// copy ROWS token rows (64 bf16 of head h each) into a row-major LDS tile; rows without a token are zero
+template <int ROWS>
+__device__ __forceinline__ void stage_tile(bf16* Ts, const bf16* __restrict__ src, int64_t brow0, int64_t ld, int h, const Seg& sg, bool keys, int lane) {
+#pragma unroll
+    for (int it = 0; it < ROWS / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const int tok = keys ? sg.tok_k(row) : sg.tok_q(row);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (tok >= 0) v = *(const uint4*)(src + (brow0 + tok) * ld + h * HD + ch * 8);
+        *(uint4*)&Ts[row * VLD + ch * 8] = v;
+    }
+}
+
+// row fragments (A or B operand of a "X rows . Y rows" product): lane -> row 16 t + (lane&15), k = 32 ks + 8 (lane>>4) ..+7
+template <int NT>
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[NT][2], const bf16* __restrict__ src, int64_t brow0, int64_t ld, int h, const Seg& sg, bool keys, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int tok = keys ? sg.tok_k(16 * t + (lane & 15)) : sg.tok_q(16 * t + (lane & 15));
+        tok = tok < 0 ? 0 : tok;
+        const bf16* p = src + (brow0 + tok) * ld + h * HD + 8 * (lane >> 4);
+        f[t][0] = *(const bf16x8*)p;
+        f[t][1] = *(const bf16x8*)(p + 32);
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+    r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];
+    r[4] = (bf16)b[0]; r[5] = (bf16)b[1]; r[6] = (bf16)b[2]; r[7] = (bf16)b[3];
+    return r;
+}
+
+template <int NQT, int NKT>
+__global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, int qgroups) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int NKTP = (NKT + 1) & ~1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int item = blockIdx.x * 4 + wid;
+    if (item >= items) return;                                   // wave-uniform: EXEC stays full for the tr-reads
+    Seg sg{a.mode, a.R, a.N, 0, 0};
+    int h, b;
+    if (a.mode == 0) { sg.f = item % a.F; h = (item / a.F) % a.H; b = item / (a.F * a.H); }
+    else { sg.qbase = (item % qgroups) * 16 * NQT; h = (item / qgroups) % a.H; b = item / (qgroups * a.H); }
+    const int64_t brow0 = (int64_t)b * a.N;
+    const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; bf16* out = (bf16*)a.out;
+    bf16* Vs = (bf16*)smraw + wid * (NKTP * 16 * VLD);
+    stage_tile<NKTP * 16>(Vs, v, brow0, a.ld, h, sg, true, lane);
+
+    bf16x8 qf[NQT][2];
+    load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
+    f32x4 st[NKT][NQT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        int tok = sg.tok_k(16 * kt + c);
+        tok = tok < 0 ? 0 : tok;
+        const bf16* p = k + (brow0 + tok) * a.ld + h * HD + 8 * g;
+        const bf16x8 k0 = *(const bf16x8*)p, k1 = *(const bf16x8*)(p + 32);
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qt][0], acc, 0, 0, 0);
+            st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qt][1], acc, 0, 0, 0);
+        }
+    }
+    float mk[NKT][4];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int tok = sg.tok_k(16 * kt + 4 * g + r); mk[kt][r] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r]; m = fmaxf(m, st[kt][qt][r]); }
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][qt][r] = expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kt][qt][r] *= inv;
+    }
+    f32x4 o[NQT][4];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NKTP / 2; ++s) {
+        const int kt0 = 2 * s, kt1 = 2 * s + 1;
+        bf16x8 pa[NQT];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) pa[qt] = pack8(st[kt0][qt], kt1 < NKT ? st[kt1 < NKT ? kt1 : kt0][qt] : zero4);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 vb = tr_pair(lds_addr(&Vs[(16 * kt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                      lds_addr(&Vs[(16 * kt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[qt], vb, o[qt][dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tok = sg.tok_q(16 * qt + 4 * g + r);
+            if (tok >= 0) {
+                bf16* orow = out + (brow0 + tok) * a.ldo + h * HD + c;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)o[qt][dt][r];
+            }
+        }
+}
+
+// backward, space mode: one wave per (b, h, frame).  Layout 1 (S^T) -> dQ; layout 2 (S) -> dK, dV.  P is recomputed.
+template <int NQT, int NKT>
+__global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int items) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int NQTP = (NQT + 1) & ~1, NKTP = (NKT + 1) & ~1, TROWS = 16 * (NQTP > NKTP ? NQTP : NKTP);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int item = blockIdx.x * 4 + wid;
+    if (item >= items) return;
+    Seg sg{0, a.R, a.N, item % a.F, 0};
+    const int h = (item / a.F) % a.H, b = item / (a.F * a.H);
+    const int64_t brow0 = (int64_t)b * a.N;
+    const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; const bf16* dout = (const bf16*)a.dout;
+    bf16* dq = (bf16*)a.dq; bf16* dk = (bf16*)a.dk; bf16* dv = (bf16*)a.dv;
+    bf16* Ts = (bf16*)smraw + wid * (TROWS * VLD);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ---------------- layout 1: keys on (g, r), queries on lane&15 -> dQ ----------------
+    {
+        bf16x8 qf[NQT][2], gf[NQT][2], kf[NKT][2], vf[NKT][2];
+        load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
+        load_row_frags<NQT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
+        load_row_frags<NKT>(kf, k, brow0, a.ld, h, sg, true, lane);
+        load_row_frags<NKT>(vf, v, brow0, a.ld, h, sg, true, lane);
+        f32x4 st[NKT][NQT], dp[NKT][NQT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[qt][0], zero4, 0, 0, 0);
+                st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], qf[qt][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt][0], gf[qt][0], zero4, 0, 0, 0);
+                dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt][1], gf[qt][1], acc, 0, 0, 0);
+            }
+        float mk[NKT][4];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int tok = sg.tok_k(16 * kt + 4 * g + r); mk[kt][r] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r]; m = fmaxf(m, st[kt][qt][r]); }
+            m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][qt][r] = expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
+            sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            float D = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][qt][r] *= inv; D += st[kt][qt][r] * dp[kt][qt][r]; }
+            D += __shfl_xor(D, 16, 64); D += __shfl_xor(D, 32, 64);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][qt][r] = st[kt][qt][r] * (dp[kt][qt][r] - D);      // dS^T
+        }
+        stage_tile<NKTP * 16>(Ts, k, brow0, a.ld, h, sg, true, lane);
+        f32x4 acc[NQT][4];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[qt][dt] = zero4;
+#pragma unroll
+        for (int s = 0; s < NKTP / 2; ++s) {
+            const int kt0 = 2 * s, kt1 = 2 * s + 1;
+            bf16x8 da[NQT];
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) da[qt] = pack8(st[kt0][qt], kt1 < NKT ? st[kt1 < NKT ? kt1 : kt0][qt] : zero4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kb = tr_pair(lds_addr(&Ts[(16 * kt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                          lds_addr(&Ts[(16 * kt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt) acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qt], kb, acc[qt][dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = sg.tok_q(16 * qt + 4 * g + r);
+                if (tok >= 0) {
+                    bf16* orow = dq + (brow0 + tok) * a.ldd + h * HD + c;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)(acc[qt][dt][r] * a.scale);
+                }
+            }
+    }
+    // ---------------- layout 2: queries on (g, r), keys on lane&15 -> dV, dK ----------------
+    {
+        bf16x8 qf[NQT][2], gf[NQT][2], kf[NKT][2], vf[NKT][2];
+        load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
+        load_row_frags<NQT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
+        load_row_frags<NKT>(kf, k, brow0, a.ld, h, sg, true, lane);
+        load_row_frags<NKT>(vf, v, brow0, a.ld, h, sg, true, lane);
+        f32x4 s2[NQT][NKT], dp[NQT][NKT];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][0], kf[kt][0], zero4, 0, 0, 0);
+                s2[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][1], kf[kt][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][0], vf[kt][0], zero4, 0, 0, 0);
+                dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][1], vf[kt][1], acc, 0, 0, 0);
+            }
+        float mk[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) { const int tok = sg.tok_k(16 * kt + c); mk[kt] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool qok = sg.tok_q(16 * qt + 4 * g + r) >= 0;
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = s2[qt][kt][r] * a.scale + mk[kt]; m = fmaxf(m, s2[qt][kt][r]); }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = expf(s2[qt][kt][r] - m); sum += s2[qt][kt][r]; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                const float inv = qok ? 1.f / sum : 0.f;                    // padded query rows contribute nothing
+                float D = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] *= inv; D += s2[qt][kt][r] * dp[qt][kt][r]; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) D += __shfl_xor(D, o, 64);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) dp[qt][kt][r] = s2[qt][kt][r] * (dp[qt][kt][r] - D);   // dS
+            }
+        // dV[key][d] = sum_q P[q][key] dO[q][d]
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            stage_tile<NQTP * 16>(Ts, pass == 0 ? dout : q, brow0, pass == 0 ? a.ldo : a.ld, h, sg, false, lane);
+            f32x4 acc[NKT][4];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc[kt][dt] = zero4;
+#pragma unroll
+            for (int s = 0; s < NQTP / 2; ++s) {
+                const int qt0 = 2 * s, qt1 = 2 * s + 1;
+                bf16x8 pa[NKT];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const f32x4& lo = pass == 0 ? s2[qt0][kt] : dp[qt0][kt];
+                    const f32x4& hi = qt1 < NQT ? (pass == 0 ? s2[qt1 < NQT ? qt1 : qt0][kt] : dp[qt1 < NQT ? qt1 : qt0][kt]) : zero4;
+                    pa[kt] = pack8(lo, hi);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 xb = tr_pair(lds_addr(&Ts[(16 * qt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                              lds_addr(&Ts[(16 * qt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[kt], xb, acc[kt][dt], 0, 0, 0);
+                }
+            }
+            const float mul = pass == 0 ? 1.f : a.scale;
+            bf16* dst = pass == 0 ? dv : dk;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * kt + 4 * g + r;
+                    if (j == 0) {
+                        float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + sg.f) * 2 + (pass == 0 ? 1 : 0)) * HD + c;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[kt][dt][r] * mul;
+                    } else if (j <= a.R) {
+                        bf16* orow = dst + (brow0 + sg.f * a.R + j) * a.ldd + h * HD + c;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)(acc[kt][dt][r] * mul);
+                    }
+                }
+        }
+    }
+}
+
 static int attn_check(const AttnArgs& a) {
     if (a.B <= 0 || a.H <= 0 || a.N <= 0) return DVLP_ERR_SHAPE;
     if (a.mode == 0) { if (a.N != 1 + a.F * a.R || a.R + 1 > KMAX) return DVLP_ERR_SHAPE; }
@@ -296,7 +643,31 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
         hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, st, a);
     } else if (dtype == DVLP_BF16) {
         static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, lds, st, a);
+        if (ld % 8 || ldo % 8) return DVLP_ERR_SHAPE;
+        // MFMA path for the frame / full segments; the single CLS query per (b, h) stays on the streaming VALU workgroup
+        bool done = false;
+#define MFWD(NQT_, NKT_, ITEMS, QG) do { const int items_ = (int)(ITEMS); const size_t l_ = (size_t)4 * (((NKT_ + 1) & ~1) * 16 * VLD) * sizeof(bf16); \
+            (void)hipFuncSetAttribute((const void*)mattn_fwd_kernel<NQT_, NKT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipLaunchKernelGGL((mattn_fwd_kernel<NQT_, NKT_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_, (int)(QG)); done = true; } while (0)
+        if (mode == 0) {
+            const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
+            if (nqt == 3 && nkt == 3) MFWD(3, 3, B * H * F, 1);
+            else if (nqt == 2 && nkt == 2) MFWD(2, 2, B * H * F, 1);
+            else if (nqt == 1 && nkt == 1) MFWD(1, 1, B * H * F, 1);
+            else if (nqt == 1 && nkt == 2) MFWD(1, 2, B * H * F, 1);
+            else if (nqt == 2 && nkt == 3) MFWD(2, 3, B * H * F, 1);
+            if (done) {   // CLS query
+                AttnArgs c = a; c.seg_begin = nseg;
+                hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(1, (unsigned)H, (unsigned)B), block, lds, st, c);
+            }
+        } else {
+            const int nkt = (int)cdiv(N, 16);
+            if (nkt == 7) MFWD(2, 7, B * H * 4, 4);
+            else if (nkt == 8) MFWD(2, 8, B * H * 4, 4);
+            else if (nkt <= 3) MFWD(3, 3, B * H, 1);
+        }
+#undef MFWD
+        if (!done) hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, lds, st, a);
     } else return DVLP_ERR_DTYPE;
     return dvlp_launch_status();
 }
@@ -326,7 +697,20 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
         if (mode == 0) hipLaunchKernelGGL(attn_bwd_cls_kernel<float>, grid2, block, lds2, st, a);
     } else if (dtype == DVLP_BF16) {
         static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void*)attn_bwd_seg_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-        hipLaunchKernelGGL(attn_bwd_seg_kernel<bf16>, grid, block, lds, st, a);
+        bool done = false;
+        if (mode == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0) {
+            const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
+            const int items = (int)(B * H * F);
+#define MBWD(NQT_, NKT_) do { const int tr_ = 16 * ((((NQT_ + 1) & ~1) > ((NKT_ + 1) & ~1)) ? ((NQT_ + 1) & ~1) : ((NKT_ + 1) & ~1)); \
+            hipLaunchKernelGGL((mattn_bwd_space_kernel<NQT_, NKT_>), dim3((unsigned)cdiv(items, 4)), block, (size_t)4 * tr_ * VLD * sizeof(bf16), st, a, items); done = true; } while (0)
+            if (nqt == 3 && nkt == 3) MBWD(3, 3);
+            else if (nqt == 2 && nkt == 2) MBWD(2, 2);
+            else if (nqt == 1 && nkt == 1) MBWD(1, 1);
+            else if (nqt == 1 && nkt == 2) MBWD(1, 2);
+            else if (nqt == 2 && nkt == 3) MBWD(2, 3);
+#undef MBWD
+        }
+        if (!done) hipLaunchKernelGGL(attn_bwd_seg_kernel<bf16>, grid, block, lds, st, a);
         if (mode == 0) hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16>, grid2, block, lds2, st, a);
     } else return DVLP_ERR_DTYPE;
     return dvlp_launch_status();

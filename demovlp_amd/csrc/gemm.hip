@@ -25,6 +25,7 @@ struct Epi {
     int flags;
     float alpha;
     int64_t sA, sB, sC, sRes, sAux;   // batch strides in elements (blockIdx.y = batch index)
+    int vec;                          // C / res / aux rows are 16-byte aligned: the bf16 epilogue may use 8-wide accesses
 };
 
 template <typename T>
@@ -47,6 +48,65 @@ __device__ __forceinline__ void epi_store(const Epi& e, T* __restrict__ C, int64
     }
     if (e.flags & EPI_ACCUM) v += to_f(C[m * ldc + n]);
     C[m * ldc + n] = from_f<T>(v);
+}
+
+// 8 consecutive columns of one output row (bf16 kernel's LDS-staged epilogue): vector loads of bias / residual / aux and
+// one 16-byte (bf16) or two 16-byte (fp32-out) stores per lane instead of eight scattered 2-byte ones.
+__device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float (&v)[8], int64_t N) {
+    if (!e.vec || n + 7 >= N) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (n + t < N) epi_store<bf16>(e, C, ldc, m, n + t, v[t]);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] *= e.alpha;
+    if (e.bias) {
+        const float4 b0 = *(const float4*)(e.bias + n), b1 = *(const float4*)(e.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (e.flags & EPI_GELU) {
+        bf16x8 pre;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_erf(v[t]); }
+        *(bf16x8*)((bf16*)e.aux + m * e.ldaux + n) = pre;
+    }
+    if (e.flags & EPI_LEAKY) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = v[t] > 0.f ? v[t] : 0.1f * v[t];
+    }
+    if (e.flags & (EPI_GELU_BWD | EPI_RELU_BWD)) {
+        const bf16x8 a = *(const bf16x8*)((const bf16*)e.aux + m * e.ldaux + n);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float h = (float)a[t];
+            v[t] = (e.flags & EPI_GELU_BWD) ? v[t] * gelu_erf_grad(h) : (h > 0.f ? v[t] : 0.f);
+        }
+    }
+    if (e.res) {
+        const bf16x8 r = *(const bf16x8*)((const bf16*)e.res + m * e.ldres + n);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += (float)r[t];
+    }
+    if (e.flags & EPI_OUT_F32) {
+        float* Cf = (float*)C + m * ldc + n;
+        if (e.flags & EPI_ACCUM) {
+            const float4 c0 = *(const float4*)Cf, c1 = *(const float4*)(Cf + 4);
+            v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+        }
+        *(float4*)Cf = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(Cf + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        return;
+    }
+    bf16* Cp = C + m * ldc + n;
+    if (e.flags & EPI_ACCUM) {
+        const bf16x8 c = *(const bf16x8*)Cp;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += (float)c[t];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
+    *(bf16x8*)Cp = o;
 }
 
 // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of tiles
@@ -201,25 +261,37 @@ __device__ __forceinline__ void h_store(bf16* __restrict__ S, const Stage4& s, i
     }
 }
 
-// MFMA 16x16x32 operand fragment of rows [rbase, rbase+16), k in [ks, ks+32) of one LDS tile.
+// Four MFMA 16x16x32 operand fragments (rows [rbase + 16 i, +16), i = 0..3; k in [ks, ks+32)) of one LDS tile.
 // lane l holds X[row = l&15][k = 8*(l>>4) + j], j = 0..7.
+static_assert(H_LDR == 136, "immediate offsets of the transposing reads below assume 272-byte k-rows");
 template <bool FORM_R>
-__device__ __forceinline__ bf16x8 h_frag(const bf16* __restrict__ S, int rbase, int ks, int lane) {
+__device__ __forceinline__ void h_frags(bf16x8 (&f)[4], const bf16* __restrict__ S, int rbase, int ks, int lane) {
     if (!FORM_R) {
-        return *(const bf16x8*)&S[(rbase + (lane & 15)) * H_LDK + ks + 8 * (lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = *(const bf16x8*)&S[(rbase + 16 * i + (lane & 15)) * H_LDK + ks + 8 * (lane >> 4)];
     } else {
         // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of block row q, columns 4p..4p+3 of a
         // 4-row x 16-column block of 16-bit elements; lane i receives column i, rows 0..3.  Block rows = k, columns = r.
-        // Group g = lane>>4 needs k = ks + 8g + {0..3} (first read) and + {4..7} (second read).
+        // Group g = lane>>4 needs k = ks + 8g + {0..3} (lo) and + {4..7} (hi = +4 k-rows = +1088 B); tile i is +32 B.
+        // All eight reads are issued back to back and retired by ONE wait.
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const unsigned a0 = (unsigned)(uintptr_t)&S[(ks + 8 * g + q) * H_LDR + rbase + 4 * pp];
-        const unsigned a1 = a0 + 4u * H_LDR * (unsigned)sizeof(bf16);
-        bf16x4 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
-        bf16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\t"
+            "ds_read_b64_tr_b16 %1, %8 offset:1088\n\t"
+            "ds_read_b64_tr_b16 %2, %8 offset:32\n\t"
+            "ds_read_b64_tr_b16 %3, %8 offset:1120\n\t"
+            "ds_read_b64_tr_b16 %4, %8 offset:64\n\t"
+            "ds_read_b64_tr_b16 %5, %8 offset:1152\n\t"
+            "ds_read_b64_tr_b16 %6, %8 offset:96\n\t"
+            "ds_read_b64_tr_b16 %7, %8 offset:1184\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3) : "v"(a0) : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
@@ -259,10 +331,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 #pragma unroll
         for (int ks = 0; ks < H_BK; ks += 32) {
             bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = h_frag<A_R>(As, wm + 16 * i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = h_frag<B_R>(Bs, wn + 16 * j, ks, lane);
+            h_frags<A_R>(af, As, wm, ks, lane);
+            h_frags<B_R>(bfr, Bs, wn, ks, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -275,17 +345,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
         }
         __syncthreads();
     }
-    // C/D map of 16x16: col = lane&15, row = 4*(lane>>4) + reg
+    // Epilogue through LDS: the wave parks its 64x64 fp32 tile (C/D map of 16x16: col = lane&15, row = 4*(lane>>4)+reg)
+    // in its own 64 x 68 float region (the K-loop buffers are free now), then every lane owns 8 consecutive columns of
+    // a row: 16-byte loads of bias/residual/aux and 16-byte stores instead of 64 scattered 2-byte stores per lane.
+    float* Ct = (float*)smem_raw + wid * (64 * 68);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
-                const int64_t n = n0 + wn + 16 * j + (lane & 15);
-                if (m < M && n < N) epi_store<bf16>(e, C, ldc, m, n, acc[i][j][r]);
-            }
+            for (int r = 0; r < 4; ++r) Ct[(16 * i + 4 * (lane >> 4) + r) * 68 + 16 * j + (lane & 15)] = acc[i][j][r];
+    // same-wave LDS accesses complete in order: no barrier needed before reading the wave's own region back
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+        const int64_t m = m0 + wm + row, n = n0 + wn + col;
+        const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (m < M && n < N) epi_store8(e, C, ldc, m, n, v, N);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -325,7 +403,15 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return DVLP_ERR_SHAPE;
     if ((flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD)) && !aux) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    Epi e{bias, res, aux, ldres, ldaux, flags, alpha, strideA, strideB, strideC, strideRes, strideAux};
+    Epi e{bias, res, aux, ldres, ldaux, flags, alpha, strideA, strideB, strideC, strideRes, strideAux, 0};
+    {
+        const int64_t cal = (flags & EPI_OUT_F32) ? 4 : 8;      // elements per 16 bytes of C
+        bool v = (ldc % cal == 0) && ((uintptr_t)C % 16 == 0) && (strideC % cal == 0);
+        if (res) v = v && (ldres % 8 == 0) && ((uintptr_t)res % 16 == 0) && (strideRes % 8 == 0);
+        if (aux) v = v && (ldaux % 8 == 0) && ((uintptr_t)aux % 16 == 0) && (strideAux % 8 == 0);
+        if (bias) v = v && ((uintptr_t)bias % 16 == 0);
+        e.vec = v ? 1 : 0;
+    }
     ProfRec rec{};
     if (g_prof) { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); rec.flops = 2.0 * M * N * K * batch; (void)hipEventRecord(rec.a, st); }
     if (dtype == DVLP_F32) {
@@ -346,6 +432,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         const int64_t ntm = cdiv(M, H_BM), ntn = cdiv(N, H_BN);
         dim3 grid((unsigned)(ntm * ntn), (unsigned)batch), block(256);
         const size_t lds = (size_t)4 * H_TILE * sizeof(bf16);
+        static_assert(4 * 64 * 68 * sizeof(float) <= (size_t)4 * H_TILE * sizeof(bf16), "epilogue staging must fit the K-loop buffers");
         // > 64 KiB of dynamic LDS must be opted into once per kernel
 #define LAUNCH_BF16(AR, BR) do { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \

@@ -99,11 +99,13 @@ struct PairArgs {
     int gate;
 };
 
+constexpr int XT = 1024;     // threads per pair workgroup: 16 waves share one S_ij tile (the tile caps residency at 1 block/CU)
+
 template <typename T>
-__device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, float* Ssm, float* rn, float* cn) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+__device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, float* Ssm, float* rn, float* cn, float* cpart /*[8][W]*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const T* S = (const T*)a.S;
-    for (int g = wid; g < a.G; g += 4) {
+    for (int g = wid; g < a.G; g += nw) {
         const T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
         float q = 0.f;
         for (int w = lane; w < a.W; w += 64) { const float v = to_f(row[w]); Ssm[g * a.Wq + w] = v; q += v * v; }
@@ -111,111 +113,124 @@ __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, flo
         if (lane == 0) rn[g] = sqrtf(q) + 1e-8f;                       // l2norm over words (loss.py:238)
     }
     __syncthreads();
+    // column norms: 8 row-slices per column, then combine
+    {
+        const int w = threadIdx.x & 127, part = threadIdx.x >> 7;
+        if (w < a.W) {
+            float q = 0.f;
+            for (int g = part; g < a.G; g += 8) { const float v = Ssm[g * a.Wq + w]; q += v * v; }
+            cpart[part * a.W + w] = q;
+        }
+    }
+    __syncthreads();
     for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
         float q = 0.f;
-        for (int g = 0; g < a.G; ++g) { const float v = Ssm[g * a.Wq + w]; q += v * v; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q += cpart[k * a.W + w];
         cn[w] = sqrtf(q) + 1e-8f;                                       // l2norm over regions (second call of :238)
     }
     __syncthreads();
 }
 
-constexpr int XMAXK = 20;   // a wave covers up to 64*20 = 1280 softmax entries (G <= 1280, W <= 1280)
-
 // softmax over n entries held as e[k] on lane (idx = lane + 64k); returns P (pre-gate) in e, P' in pp; s = sum of gated P
-__device__ __forceinline__ void focal_softmax(float (&e)[XMAXK], float (&pp)[XMAXK], int n, int nk, int lane, int gate, float& s_out) {
+template <int NK>
+__device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], int n, int lane, int gate, float& s_out) {
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < XMAXK; ++k) if (k < nk) m = fmaxf(m, lane + 64 * k < n ? e[k] : -INFINITY);
+    for (int k = 0; k < NK; ++k) m = fmaxf(m, lane + 64 * k < n ? e[k] : -INFINITY);
     m = wave_max(m);
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < XMAXK; ++k) if (k < nk) { e[k] = lane + 64 * k < n ? expf(e[k] - m) : 0.f; sum += e[k]; }
-    sum = wave_sum(sum);
+    for (int k = 0; k < NK; ++k) { e[k] = lane + 64 * k < n ? expf(e[k] - m) : 0.f; sum += e[k]; }
+    const float inv = 1.f / wave_sum(sum);
     float psum = 0.f;
 #pragma unroll
-    for (int k = 0; k < XMAXK; ++k) if (k < nk) { e[k] = e[k] / sum; psum += e[k]; }
+    for (int k = 0; k < NK; ++k) { e[k] = e[k] * inv; psum += e[k]; }
     psum = wave_sum(psum);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < XMAXK; ++k) if (k < nk) {
+    for (int k = 0; k < NK; ++k) {
         const float h = gate ? ((e[k] * (float)n - psum) > 0.f ? 1.f : 0.f) : 1.f;   // focal_equal (loss.py:274-283)
         pp[k] = h * e[k];
         s += pp[k];
     }
     s = wave_sum(s);
+    const float is = 1.f / s;
 #pragma unroll
-    for (int k = 0; k < XMAXK; ++k) if (k < nk) pp[k] = pp[k] / s;
+    for (int k = 0; k < NK; ++k) pp[k] = pp[k] * is;
     s_out = s;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void xsoftmax_fwd_kernel(PairArgs a) {
+template <typename T, int NKG, int NKW>
+__global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int j = blockIdx.x, i = blockIdx.y;
-    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G;
-    pair_load_S<T>(a, i, j, Ssm, rn, cn);
+    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* cpart = cn + a.W;
+    pair_load_S<T>(a, i, j, Ssm, rn, cn, cpart);
     T* P1 = (T*)a.P1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;
     T* P2 = (T*)a.P2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;
     const float* mimg = a.mimg + (int64_t)i * a.G;
     const float* mcap = a.mcap + (int64_t)j * a.W;
-    const int nkg = (a.G + 63) / 64, nkw = (a.W + 63) / 64, nkgp = (a.Gp + 63) / 64, nkwp = (a.Wp + 63) / 64;
     // image -> text: for each word, softmax over regions (the caption-mask term is constant along this axis)
-    for (int w = wid; w < a.Wp; w += 4) {
-        float e[XMAXK], pp[XMAXK], s;
+    for (int w = wid; w < a.Wp; w += nw) {
+        float e[NKG], pp[NKG], s;
         if (w < a.W) {
 #pragma unroll
-            for (int k = 0; k < XMAXK; ++k) if (k < nkg) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
-            focal_softmax(e, pp, a.G, nkg, lane, a.gate, s);
+            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
+            focal_softmax<NKG>(e, pp, a.G, lane, a.gate, s);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) pp[k] = 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkgp) { const int g = lane + 64 * k; if (g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(w < a.W && g < a.G ? pp[k] : 0.f); }
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(g < a.G ? pp[k] : 0.f); }
     }
     // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
-    for (int g = wid; g < a.G; g += 4) {
-        float e[XMAXK], pp[XMAXK], s;
+    for (int g = wid; g < a.G; g += nw) {
+        float e[NKW], pp[NKW], s;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
-        focal_softmax(e, pp, a.W, nkw, lane, a.gate, s);
+        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
+        focal_softmax<NKW>(e, pp, a.W, lane, a.gate, s);
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkwp) { const int w = lane + 64 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
     }
 }
 
 // backward of the softmax stage; leaves dS_raw in S (see file header)
-template <typename T>
-__global__ __launch_bounds__(256) void xsoftmax_bwd_kernel(PairArgs a) {
+template <typename T, int NKG, int NKW>
+__global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int j = blockIdx.x, i = blockIdx.y;
-    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* rowdot = cn + a.W; float* coldot = rowdot + a.G;
+    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* cpart = cn + a.W;
+    float* rowdot = cpart + 8 * a.W; float* coldot = rowdot + a.G;
     for (int t = threadIdx.x; t < a.G; t += blockDim.x) rowdot[t] = 0.f;
     for (int t = threadIdx.x; t < a.W; t += blockDim.x) coldot[t] = 0.f;
-    pair_load_S<T>(a, i, j, Ssm, rn, cn);
+    pair_load_S<T>(a, i, j, Ssm, rn, cn, cpart);
     T* D1 = (T*)a.dP1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;     // in: dP1, out: dA / rn
     T* D2 = (T*)a.dP2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;      // in: dP2, out: dA2 / cn
     const float* mimg = a.mimg + (int64_t)i * a.G;
     const float* mcap = a.mcap + (int64_t)j * a.W;
-    const int nkg = (a.G + 63) / 64, nkw = (a.W + 63) / 64;
-    for (int w = wid; w < a.W; w += 4) {
-        float e[XMAXK], pp[XMAXK], s;
+    for (int w = wid; w < a.W; w += nw) {
+        float e[NKG], pp[NKG], s;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkg) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
-        focal_softmax(e, pp, a.G, nkg, lane, a.gate, s);
-        float dpp[XMAXK], d1 = 0.f;
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
+        focal_softmax<NKG>(e, pp, a.G, lane, a.gate, s);
+        float dpp[NKG], d1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkg) { const int g = lane + 64 * k; dpp[k] = g < a.G ? to_f(D1[(int64_t)w * a.Gp + g]) : 0.f; d1 += dpp[k] * pp[k]; }
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; dpp[k] = g < a.G ? to_f(D1[(int64_t)w * a.Gp + g]) : 0.f; d1 += dpp[k] * pp[k]; }
         d1 = wave_sum(d1);
         float d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkg) {
+        for (int k = 0; k < NKG; ++k) {
             // P' = T / s, T = H P  ->  dP = H (dP' - <dP', P'>) / s   (H is a constant gate; pp > 0 <=> H = 1)
             dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f;
             d2 += dpp[k] * e[k];
         }
         d2 = wave_sum(d2);
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkg) {
+        for (int k = 0; k < NKG; ++k) {
             const int g = lane + 64 * k;
             if (g < a.G) {
                 const float dA = a.lam * e[k] * (dpp[k] - d2);           // softmax backward, times lambda
@@ -224,21 +239,21 @@ __global__ __launch_bounds__(256) void xsoftmax_bwd_kernel(PairArgs a) {
             }
         }
     }
-    for (int g = wid; g < a.G; g += 4) {
-        float e[XMAXK], pp[XMAXK], s;
+    for (int g = wid; g < a.G; g += nw) {
+        float e[NKW], pp[NKW], s;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
-        focal_softmax(e, pp, a.W, nkw, lane, a.gate, s);
-        float dpp[XMAXK], d1 = 0.f;
+        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
+        focal_softmax<NKW>(e, pp, a.W, lane, a.gate, s);
+        float dpp[NKW], d1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { const int w = lane + 64 * k; dpp[k] = w < a.W ? to_f(D2[(int64_t)g * a.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
+        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; dpp[k] = w < a.W ? to_f(D2[(int64_t)g * a.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
         d1 = wave_sum(d1);
         float d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkw) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f; d2 += dpp[k] * e[k]; }
+        for (int k = 0; k < NKW; ++k) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f; d2 += dpp[k] * e[k]; }
         d2 = wave_sum(d2);
 #pragma unroll
-        for (int k = 0; k < XMAXK; ++k) if (k < nkw) {
+        for (int k = 0; k < NKW; ++k) {
             const int w = lane + 64 * k;
             if (w < a.W) {
                 const float dA = a.lam * e[k] * (dpp[k] - d2);
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256) void xsoftmax_bwd_kernel(PairArgs a) {
     __syncthreads();
     // A = S / rn with rn = |S_row| + eps:  dS = dA/rn - S <dA,S>_row / (rn^2 (rn - eps)); same along columns; then LeakyReLU'
     T* S = (T*)a.S;
-    for (int g = wid; g < a.G; g += 4) {
+    for (int g = wid; g < a.G; g += nw) {
         const float r = rn[g], cr = rowdot[g] / (r * r * fmaxf(r - 1e-8f, 1e-30f));
         T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
         for (int w = lane; w < a.W; w += 64) {
@@ -395,9 +410,32 @@ __global__ __launch_bounds__(256) void xprep_bwd_kernel(int64_t outer, int64_t i
 // ------------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int XMAX_NKG = 6, XMAX_NKW = 2;    // G <= 384, W <= 128 (the S_ij tile must fit the 160 KiB LDS anyway)
 static size_t pair_lds(int64_t G, int64_t W, int bwd) {
     const int64_t Wq = W | 1;
-    return (size_t)(G * Wq + G + W + (bwd ? G + W : 0)) * sizeof(float);
+    return (size_t)(G * Wq + G + W + 8 * W + (bwd ? G + W : 0)) * sizeof(float);
+}
+
+// dispatch the per-pair kernels on the compile-time chunk counts NKG = ceil(G/64), NKW = ceil(W/64)
+template <typename T, int NKG>
+static void launch_pair_w(bool bwd, int nkw, dim3 grid, size_t lds, hipStream_t st, const PairArgs& pa) {
+#define XLAUNCH(NKW_) do { \
+        auto kf = xsoftmax_fwd_kernel<T, NKG, NKW_>; auto kb = xsoftmax_bwd_kernel<T, NKG, NKW_>; \
+        (void)hipFuncSetAttribute((const void*)(bwd ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (bwd) hipLaunchKernelGGL(kb, grid, dim3(XT), lds, st, pa); else hipLaunchKernelGGL(kf, grid, dim3(XT), lds, st, pa); } while (0)
+    if (nkw == 1) XLAUNCH(1); else XLAUNCH(2);
+#undef XLAUNCH
+}
+template <typename T>
+static void launch_pair(bool bwd, int nkg, int nkw, dim3 grid, size_t lds, hipStream_t st, const PairArgs& pa) {
+    switch (nkg) {
+        case 1: launch_pair_w<T, 1>(bwd, nkw, grid, lds, st, pa); break;
+        case 2: launch_pair_w<T, 2>(bwd, nkw, grid, lds, st, pa); break;
+        case 3: launch_pair_w<T, 3>(bwd, nkw, grid, lds, st, pa); break;
+        case 4: launch_pair_w<T, 4>(bwd, nkw, grid, lds, st, pa); break;
+        case 5: launch_pair_w<T, 5>(bwd, nkw, grid, lds, st, pa); break;
+        default: launch_pair_w<T, 6>(bwd, nkw, grid, lds, st, pa); break;
+    }
 }
 #define XG(...) do { int rc_ = dvlp_gemm_batched(__VA_ARGS__); if (rc_) return rc_; } while (0)
 
@@ -405,7 +443,7 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
                               const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd,
                               void* stream) {
     dvlp_clear_status();
-    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAXK || W > 64 * XMAXK) return DVLP_ERR_SHAPE;
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 64 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
     if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;      // long-video (G > ~380) tiling: not in round 1
     hipStream_t st = (hipStream_t)stream;
@@ -433,10 +471,9 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.lam = lam; pa.gate = gate;
     {
         const size_t lds = pair_lds(G, W, 0);
-        static bool o1 = false, o2 = false;
-        if (dtype == DVLP_F32) { if (!o1) { o1 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
-        else { if (!o2) { o2 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
-        DT(xsoftmax_fwd_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, lds, st, pa);
+        const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 64);
+        if (dtype == DVLP_F32) launch_pair<float>(false, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
+        else launch_pair<bf16>(false, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
     }
     // wc[i] [(Bj*Wp) x d] = P1[i] [(Bj*Wp) x G] . Chat_i [G x d]
     XG(dtype, 0, 1, Bj * Wp, XD, G, P1, Gp, chat, XD, wc, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, G * XD,
@@ -456,7 +493,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
                               const float* mimg, const float* mcap, float lam, int gate, const float* dscores, void* workspace,
                               void* dC, void* dQ, void* stream) {
     dvlp_clear_status();
-    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAXK || W > 64 * XMAXK) return DVLP_ERR_SHAPE;
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 64 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
     if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -485,10 +522,9 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.lam = lam; pa.gate = gate;
     {
         const size_t lds = pair_lds(G, W, 1);
-        static bool o1 = false, o2 = false;
-        if (dtype == DVLP_F32) { if (!o1) { o1 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
-        else { if (!o2) { o2 = true; (void)hipFuncSetAttribute((const void*)xsoftmax_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
-        DT(xsoftmax_bwd_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, lds, st, pa);   // S <- dS_raw
+        const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 64);
+        if (dtype == DVLP_F32) launch_pair<float>(true, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);      // S <- dS_raw
+        else launch_pair<bf16>(true, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
     }
     // dChat_i [G x d] = P1[i]^T [G x Bj*Wp] . dwc[i] [Bj*Wp x d]  +  dSraw[i] [G x Bj*Wp] . Qhat [Bj*Wp x d]
     XG(dtype, 1, 1, G, XD, Bj * Wp, P1, Gp, wc, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, Bj * Wp * XD,

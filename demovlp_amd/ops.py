@@ -136,8 +136,8 @@ def layernorm_fwd(x2d, gamma, beta, eps, want_relu=False):
 def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None):
     M, D = x2d.shape
     dx = torch.empty_like(x2d)
-    dgamma = torch.empty(D, device=x2d.device, dtype=torch.float32)
-    dbeta = torch.empty_like(dgamma)
+    gb = torch.empty(2 * D, device=x2d.device, dtype=torch.float32)      # contiguous pair -> one reduction launch
+    dgamma, dbeta = gb[:D], gb[D:]
     ws = _workspace("ln", (call("dvlp_layernorm_bwd_blocks", M) + 1) * 2 * D, x2d.device)
     call("dvlp_layernorm_bwd", dt(x2d), M, D, p(dy2d), p(x2d), p(gamma), p(mean), p(rstd), p(dres), p(dx), p(dgamma), p(dbeta),
          p(ws), 0, stream())
