@@ -618,6 +618,170 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
     }
 }
 
+
+// backward, full (text) mode: one workgroup per (b, h); K, Q and dO tiles are staged once in LDS and shared; wave w owns
+// query tiles {2w, 2w+1} for dQ (layout 1) and key tiles {2w, 2w+1} for dK / dV (layout 2).  NT = ceil(L / 16) <= 8.
+template <int NT>
+__global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int NTP = (NT + 1) & ~1, ROWS = 16 * NTP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int h = blockIdx.x, b = blockIdx.y;
+    Seg sg{1, a.R, a.N, 0, 0};
+    const int64_t brow0 = (int64_t)b * a.N;
+    const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; const bf16* dout = (const bf16*)a.dout;
+    bf16* dq = (bf16*)a.dq; bf16* dk = (bf16*)a.dk; bf16* dv = (bf16*)a.dv;
+    bf16* Ks = (bf16*)smraw; bf16* Qs = Ks + ROWS * VLD; bf16* Gs = Qs + ROWS * VLD;
+    float* stats = (float*)(Gs + ROWS * VLD);      // [ROWS][3]: row max, 1/row sum, D = sum_k P dP  (written by layout 1)
+    // cooperative staging: wave w copies rows [w*ROWS/4, (w+1)*ROWS/4) of each tile
+    {
+        const Seg all = sg;
+#pragma unroll
+        for (int it = 0; it < ROWS / 32; ++it) {
+            const int row = wid * (ROWS / 4) + it * 8 + (lane >> 3), ch = lane & 7;
+            const int tok = all.tok_k(row);
+            uint4 kv = make_uint4(0u, 0u, 0u, 0u), qv = kv, gv = kv;
+            if (tok >= 0) {
+                kv = *(const uint4*)(k + (brow0 + tok) * a.ld + h * HD + ch * 8);
+                qv = *(const uint4*)(q + (brow0 + tok) * a.ld + h * HD + ch * 8);
+                gv = *(const uint4*)(dout + (brow0 + tok) * a.ldo + h * HD + ch * 8);
+            }
+            *(uint4*)&Ks[row * VLD + ch * 8] = kv; *(uint4*)&Qs[row * VLD + ch * 8] = qv; *(uint4*)&Gs[row * VLD + ch * 8] = gv;
+        }
+    }
+    __syncthreads();
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // row fragments of tile t (16 rows, both k-steps) straight from the LDS tiles (row-major, 16-byte reads)
+    auto rowfrag = [&](const bf16* T, int t, int ks) { return *(const bf16x8*)&T[(16 * t + c) * VLD + 32 * ks + 8 * g]; };
+    auto vfrag = [&](int t, int ks) {          // V rows are not staged: read them from global
+        int tok = sg.tok_k(16 * t + c); tok = tok < 0 ? 0 : tok;
+        return *(const bf16x8*)(v + (brow0 + tok) * a.ld + h * HD + 32 * ks + 8 * g);
+    };
+    // ---------------- layout 1: this wave's query tiles -> dQ ----------------
+#pragma unroll 1
+    for (int qi = 0; qi < 2; ++qi) {
+        const int qt = 2 * wid + qi;
+        if (qt >= NT) break;
+        const bf16x8 q0 = rowfrag(Qs, qt, 0), q1 = rowfrag(Qs, qt, 1), g0 = rowfrag(Gs, qt, 0), g1 = rowfrag(Gs, qt, 1);
+        f32x4 st[NT], dp[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Ks, kt, 0), q0, zero4, 0, 0, 0);
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Ks, kt, 1), q1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag(kt, 0), g0, zero4, 0, 0, 0);
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag(kt, 1), g1, acc, 0, 0, 0);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = sg.tok_k(16 * kt + 4 * g + r);
+                st[kt][r] = st[kt][r] * a.scale + (tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY);
+                m = fmaxf(m, st[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][r] = expf(st[kt][r] - m); sum += st[kt][r]; }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        float D = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][r] *= inv; D += st[kt][r] * dp[kt][r]; }
+        D += __shfl_xor(D, 16, 64); D += __shfl_xor(D, 32, 64);
+        if (g == 0) { float* sp = stats + (16 * qt + c) * 3; sp[0] = m; sp[1] = inv; sp[2] = D; }
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * (dp[kt][r] - D);
+        f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+        for (int s = 0; s < NTP / 2; ++s) {
+            const int kt0 = 2 * s, kt1 = 2 * s + 1;
+            const bf16x8 da = pack8(st[kt0], kt1 < NT ? st[kt1 < NT ? kt1 : kt0] : zero4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kb = tr_pair(lds_addr(&Ks[(16 * kt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                          lds_addr(&Ks[(16 * kt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, kb, acc[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tok = sg.tok_q(16 * qt + 4 * g + r);
+            if (tok >= 0) {
+                bf16* orow = dq + (brow0 + tok) * a.ldd + h * HD + c;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)(acc[dt][r] * a.scale);
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- layout 2: this wave's key tiles -> dV, dK ----------------
+#pragma unroll 1
+    for (int ki = 0; ki < 2; ++ki) {
+        const int kt = 2 * wid + ki;
+        if (kt >= NT) break;
+        const bf16x8 k0 = rowfrag(Ks, kt, 0), k1 = rowfrag(Ks, kt, 1), v0 = vfrag(kt, 0), v1 = vfrag(kt, 1);
+        const int ktok = sg.tok_k(16 * kt + c);
+        const float mk = ktok >= 0 ? a.addmask[brow0 + ktok] : -INFINITY;
+        f32x4 s2[NT], dp[NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Qs, qt, 0), k0, zero4, 0, 0, 0);
+            s2[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Qs, qt, 1), k1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Gs, qt, 0), v0, zero4, 0, 0, 0);
+            dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Gs, qt, 1), v1, acc, 0, 0, 0);
+        }
+        // row statistics of query q = 16 qt + 4 g + r (over ALL keys) come from layout 1 through LDS
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = 16 * qt + 4 * g + r;
+                const bool qok = sg.tok_q(qi) >= 0;
+                const float* sp = stats + qi * 3;
+                const float p = qok ? expf(s2[qt][r] * a.scale + mk - sp[0]) * sp[1] : 0.f;
+                s2[qt][r] = p;                                   // P[q][key]
+                dp[qt][r] = p * (dp[qt][r] - sp[2]);             // dS[q][key]
+            }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const bf16* Ts = pass == 0 ? Gs : Qs;
+            f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+            for (int s = 0; s < NTP / 2; ++s) {
+                const int qt0 = 2 * s, qt1 = 2 * s + 1;
+                const f32x4& lo = pass == 0 ? s2[qt0] : dp[qt0];
+                const f32x4& hi = qt1 < NT ? (pass == 0 ? s2[qt1 < NT ? qt1 : qt0] : dp[qt1 < NT ? qt1 : qt0]) : zero4;
+                const bf16x8 pa = pack8(lo, hi);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 xb = tr_pair(lds_addr(&Ts[(16 * qt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                              lds_addr(&Ts[(16 * qt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, xb, acc[dt], 0, 0, 0);
+                }
+            }
+            const float mul = pass == 0 ? 1.f : a.scale;
+            bf16* dst = pass == 0 ? dv : dk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = sg.tok_k(16 * kt + 4 * g + r);
+                if (tok >= 0) {
+                    bf16* orow = dst + (brow0 + tok) * a.ldd + h * HD + c;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)(acc[dt][r] * mul);
+                }
+            }
+        }
+    }
+}
+
 static int attn_check(const AttnArgs& a) {
     if (a.B <= 0 || a.H <= 0 || a.N <= 0) return DVLP_ERR_SHAPE;
     if (a.mode == 0) { if (a.N != 1 + a.F * a.R || a.R + 1 > KMAX) return DVLP_ERR_SHAPE; }
@@ -709,6 +873,16 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
             else if (nqt == 1 && nkt == 2) MBWD(1, 2);
             else if (nqt == 2 && nkt == 3) MBWD(2, 3);
 #undef MBWD
+        }
+        if (mode == 1 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0) {
+            const int nt = (int)cdiv(N, 16);
+#define MFULL(NT_) do { const size_t l_ = (size_t)3 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16) + (size_t)16 * ((NT_ + 1) & ~1) * 3 * sizeof(float); \
+            (void)hipFuncSetAttribute((const void*)mattn_bwd_full_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipLaunchKernelGGL((mattn_bwd_full_kernel<NT_>), dim3((unsigned)H, (unsigned)B), block, l_, st, a); done = true; } while (0)
+            if (nt == 7) MFULL(7);
+            else if (nt == 8) MFULL(8);
+            else if (nt == 3) MFULL(3);
+#undef MFULL
         }
         if (!done) hipLaunchKernelGGL(attn_bwd_seg_kernel<bf16>, grid, block, lds, st, a);
         if (mode == 0) hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16>, grid2, block, lds2, st, a);

@@ -28,8 +28,11 @@ struct Epi {
     int vec;                          // C / res / aux rows are 16-byte aligned: the bf16 epilogue may use 8-wide accesses
 };
 
+// Scalar epilogue.  Deliberately NOT inlined: it is called 64x per thread from the f32 kernel and from the ragged-edge path
+// of the bf16 kernel; inlining every copy (each with erff/expf expansions) made the kernels ~230 KB of code, far past the
+// instruction cache, and the K loop paid for it in fetch stalls (measured: 10 % MFMA utilisation).
 template <typename T>
-__device__ __forceinline__ void epi_store(const Epi& e, T* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float v) {
+__device__ __attribute__((noinline)) void epi_store(const Epi& e, T* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float v) {
     v *= e.alpha;
     if (e.bias) v += e.bias[n];
     if (e.flags & EPI_GELU) {
@@ -116,6 +119,19 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
+// Tile order inside that run: groups of GROUP_M row panels, column-major inside a group, so the ~64 workgroups resident
+// on one XCD (32 CUs x 2) cover an ~8 x 8 patch of tiles: 16 operand panels (3 MB at K = 768) stay in the 4 MiB L2
+// instead of the 20-27 panels a row-major sweep of an 18-24 tile wide output touches.
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_of(int64_t wg, int64_t ntm, int64_t ntn, int64_t& tm, int64_t& tn) {
+    const int64_t per_group = GROUP_M * ntn;
+    const int64_t grp = wg / per_group, first = grp * GROUP_M;
+    const int64_t gsz = ntm - first < GROUP_M ? ntm - first : GROUP_M;
+    const int64_t in = wg % per_group;
+    tm = first + in % gsz;
+    tn = in / gsz;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // f32 kernel
 // ------------------------------------------------------------------------------------------------------------------
@@ -169,7 +185,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
     __shared__ __attribute__((aligned(16))) float Bs[F_BK][F_LD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (wg / ntn) * F_BM, n0 = (wg % ntn) * F_BN;
+    int64_t tm_, tn_;
+    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
+    const int64_t m0 = tm_ * F_BM, n0 = tn_ * F_BN;
     A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC;
     if (e.res) e.res = (const float*)e.res + blockIdx.y * e.sRes;
     if (e.aux) e.aux = (float*)e.aux + blockIdx.y * e.sAux;
@@ -222,10 +240,11 @@ constexpr int H_TILE = (H_BM * H_LDK > H_BK * H_LDR ? H_BM * H_LDK : H_BK * H_LD
 
 struct Stage4 { uint4 v[4]; };
 
-// global -> registers (4 x 16 B per thread per operand).  Out-of-range rows / k are zero-filled.
+// global -> registers (4 x 16 B per thread per operand), SAFE form: out-of-range rows / k are zero-filled element-wise.
+// Only used for operands whose row count is not a multiple of 8 (divergent branches in the K loop cost ~2x).
 template <bool FORM_R>
-__device__ __forceinline__ void h_load(Stage4& s, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
-                                       int64_t K, int tid) {
+__device__ __forceinline__ void h_load_safe(Stage4& s, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
+                                            int64_t K, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = tid + 256 * i;
@@ -237,7 +256,6 @@ __device__ __forceinline__ void h_load(Stage4& s, const bf16* __restrict__ X, in
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (ok) v = *(const uint4*)src;
         else {
-            // ragged edge: element-wise (rare: last tile of M/N/K only)
             bf16 t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -248,6 +266,44 @@ __device__ __forceinline__ void h_load(Stage4& s, const bf16* __restrict__ X, in
             v = *(uint4*)t;
         }
         s.v[i] = v;
+    }
+}
+
+// FAST form: no per-lane branches in the K loop.  Rows past the edge are CLAMPED onto the last valid row / 8-row chunk
+// (they only feed output rows >= M or columns >= N, which are never stored); only the K tail needs zeros, and that is a
+// workgroup-uniform case taken for the last K tile alone.
+template <bool FORM_R>
+__device__ __forceinline__ void h_load_fast(Stage4& s, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
+                                            int64_t K, int tid, bool ktail) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        if (FORM_R) {
+            const int k = p >> 4, rq = (p & 15) * 8;
+            int64_t gr = r0 + rq;
+            gr = gr > R - 8 ? R - 8 : gr;
+            int64_t gk = k0 + k;
+            if (!ktail) s.v[i] = *(const uint4*)(X + gk * ld + gr);
+            else {
+                const bool in = gk < K;
+                gk = in ? gk : K - 1;
+                uint4 v = *(const uint4*)(X + gk * ld + gr);
+                s.v[i] = in ? v : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {
+            const int row = p >> 3, kq = (p & 7) * 8;
+            int64_t gr = r0 + row;
+            gr = gr > R - 1 ? R - 1 : gr;
+            int64_t gk = k0 + kq;
+            if (!ktail) s.v[i] = *(const uint4*)(X + gr * ld + gk);
+            else {
+                // K is a multiple of 8 on this path, so an 8-element chunk is entirely inside or entirely outside
+                const bool in = gk < K;
+                gk = in ? gk : K - 8;
+                uint4 v = *(const uint4*)(X + gr * ld + gk);
+                s.v[i] = in ? v : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
     }
 }
 
@@ -295,15 +351,17 @@ __device__ __forceinline__ void h_frags(bf16x8 (&f)[4], const bf16* __restrict__
     }
 }
 
-template <bool A_R, bool B_R>
+template <bool A_R, bool B_R, bool SAFE>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
                                                         const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
-                                                        Epi e, int64_t ntn) {
+                                                        Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16* smem = (bf16*)smem_raw;                        // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (wg / ntn) * H_BM, n0 = (wg % ntn) * H_BN;
+    int64_t tm_, tn_;
+    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
+    const int64_t m0 = tm_ * H_BM, n0 = tn_ * H_BN;
     A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
     if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
     if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
@@ -314,20 +372,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int64_t nk = (K + H_BK - 1) / H_BK;
+    // split-K: blockIdx.z owns k in [kbeg, kend); partial tiles go to fp32 slabs and a second kernel applies the epilogue
+    const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    const int64_t nk = (kend - kbeg + H_BK - 1) / H_BK;
+    const bool has_tail = (kend - kbeg) % H_BK != 0;
     Stage4 ra, rb;
-    h_load<A_R>(ra, A, lda, m0, 0, M, K, tid);
-    h_load<B_R>(rb, B, ldb, n0, 0, N, K, tid);
+    auto load_tile = [&](int64_t kt) {
+        const int64_t k0 = kbeg + kt * H_BK;
+        if (SAFE) {
+            h_load_safe<A_R>(ra, A, lda, m0, k0, M, kend, tid);
+            h_load_safe<B_R>(rb, B, ldb, n0, k0, N, kend, tid);
+        } else {
+            const bool tail = has_tail && kt == nk - 1;
+            h_load_fast<A_R>(ra, A, lda, m0, k0, M, kend, tid, tail);
+            h_load_fast<B_R>(rb, B, ldb, n0, k0, N, kend, tid, tail);
+        }
+    };
+    load_tile(0);
     h_store<A_R>(smem, ra, tid);
     h_store<B_R>(smem + H_TILE, rb, tid);
     __syncthreads();
     for (int64_t kt = 0; kt < nk; ++kt) {
         const bf16* As = smem + (kt & 1) * 2 * H_TILE;
         const bf16* Bs = As + H_TILE;
-        if (kt + 1 < nk) {
-            h_load<A_R>(ra, A, lda, m0, (kt + 1) * H_BK, M, K, tid);
-            h_load<B_R>(rb, B, ldb, n0, (kt + 1) * H_BK, N, K, tid);
-        }
+        if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < H_BK; ks += 32) {
             bf16x8 af[4], bfr[4];
@@ -356,14 +424,48 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ct[(16 * i + 4 * (lane >> 4) + r) * 68 + 16 * j + (lane & 15)] = acc[i][j][r];
     // same-wave LDS accesses complete in order: no barrier needed before reading the wave's own region back
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
         const int64_t m = m0 + wm + row, n = n0 + wn + col;
         const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
         float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        if (m < M && n < N) epi_store8(e, C, ldc, m, n, v, N);
+        if (m < M && n < N) {
+            if (slab) {
+                float* dst = slab + ((int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M + m) * N + n;
+                if ((N & 3) == 0 && n + 7 < N) { *(float4*)dst = c0; *(float4*)(dst + 4) = c1; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) if (n + t < N) dst[t] = v[t];
+                }
+            } else epi_store8(e, C, ldc, m, n, v, N);
+        }
     }
+}
+
+// second stage of a split-K GEMM: sum the S fp32 slabs of one output and apply the epilogue (8 columns per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int S, const float* __restrict__ slab, bf16* __restrict__ C,
+                                                            int64_t ldc, Epi e) {
+    const int64_t n8 = (N + 7) / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * n8) return;
+    const int64_t m = idx / n8, n = (idx % n8) * 8;
+    const int64_t batch = blockIdx.y;
+    C += batch * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
+    if (e.res) e.res = (const bf16*)e.res + batch * e.sRes;
+    if (e.aux) e.aux = (bf16*)e.aux + batch * e.sAux;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float* src = slab + ((batch * S + s) * M + m) * N + n;
+        if ((N & 3) == 0 && n + 7 < N) {
+            const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (n + t < N) v[t] += src[t];
+        }
+    }
+    epi_store8(e, C, ldc, m, n, v, N);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -371,6 +473,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 // ------------------------------------------------------------------------------------------------------------------
 int g_dvlp_last_hip_error = 0;
 extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipError_t)g_dvlp_last_hip_error); }
+
+// caller-provided scratch for split-K slabs (dvlp_set_workspace); nullptr disables splitting
+static float* g_ws = nullptr;
+static int64_t g_ws_bytes = 0;
+extern "C" int dvlp_set_workspace(void* ptr, int64_t bytes) { g_ws = (float*)ptr; g_ws_bytes = ptr ? bytes : 0; return DVLP_OK; }
 
 struct ProfRec { hipEvent_t a, b; double flops; };
 static bool g_prof = false;
@@ -430,18 +537,38 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         // 16-byte vector loads need 8-element-aligned leading dims and base pointers
         if (lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16 || strideA % 8 || strideB % 8) return DVLP_ERR_SHAPE;
         const int64_t ntm = cdiv(M, H_BM), ntn = cdiv(N, H_BN);
-        dim3 grid((unsigned)(ntm * ntn), (unsigned)batch), block(256);
         const size_t lds = (size_t)4 * H_TILE * sizeof(bf16);
         static_assert(4 * 64 * 68 * sizeof(float) <= (size_t)4 * H_TILE * sizeof(bf16), "epilogue staging must fit the K-loop buffers");
+        // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
+        // K so that ~3 workgroups land on every CU; partials go through fp32 slabs (deterministic, no float atomics).
+        int64_t S = 1;
+        const int64_t tiles = ntm * ntn * batch;
+        if (g_ws && tiles < 384 && K >= 1024) {
+            S = (768 + tiles - 1) / tiles;
+            if (S > K / 256) S = K / 256;
+            if (S > 32) S = 32;
+            while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;
+        }
+        int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;
+        S = cdiv(K, kchunk);
+        float* slab = S > 1 ? g_ws : nullptr;
+        dim3 grid((unsigned)(ntm * ntn), (unsigned)batch, (unsigned)S), block(256);
+        // the branch-free loader clamps rows: form-K operands need >= 1 row, form-R operands a row count that is a multiple of 8
+        const bool safe = (transA ? (M % 8 != 0 || M < 8) : false) || (transB ? (N % 8 != 0 || N < 8) : false) || K < 8 || K % 8 != 0;
         // > 64 KiB of dynamic LDS must be opted into once per kernel
-#define LAUNCH_BF16(AR, BR) do { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
-        hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
-                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn); } while (0)
+#define LAUNCH_BF16_(AR, BR, SF) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
+        hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
+#define LAUNCH_BF16(AR, BR) do { if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         if (!transA && !transB) LAUNCH_BF16(false, false);
         else if (!transA && transB) LAUNCH_BF16(false, true);
         else if (transA && transB) LAUNCH_BF16(true, true);
         else LAUNCH_BF16(true, false);
+        if (S > 1)
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M * cdiv(N, 8), 256), (unsigned)batch), dim3(256), 0, st, M, N, (int)S,
+                               (const float*)slab, (bf16*)C, ldc, e);
+#undef LAUNCH_BF16_
 #undef LAUNCH_BF16
     } else {
         return DVLP_ERR_DTYPE;

@@ -47,6 +47,8 @@ def gemm(a, b, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, out
          aux=None, flags=0, alpha=1.0, out_f32=False, dtype=None):
     """C[M,N] = epi(alpha * op(A) op(B)^T).  a/b/out/res/aux are tensors whose data_ptr is the matrix origin."""
     d = dt(a) if dtype is None else dtype
+    if d == BF16:
+        ensure_gemm_workspace(a.device)
     lda = lda if lda is not None else (M if trans_a else K)
     ldb = ldb if ldb is not None else (N if trans_b else K)
     if out is None:
@@ -57,6 +59,19 @@ def gemm(a, b, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, out
     call("dvlp_gemm", d, int(trans_a), int(trans_b), M, N, K, p(a), lda, p(b), ldb, p(out), ldc, p(bias), p(res),
          N if res is not None else 0, p(aux), N if aux is not None else 0, flags, float(alpha), stream())
     return out
+
+
+_GEMM_WS = {}
+
+
+def ensure_gemm_workspace(device, mbytes=160):
+    """Register (once per device) the scratch the split-K GEMM uses for its fp32 partial slabs."""
+    key = str(device)
+    if key not in _GEMM_WS:
+        t = torch.empty(mbytes * 1024 * 1024, device=device, dtype=torch.uint8)
+        _GEMM_WS[key] = t
+        call("dvlp_set_workspace", p(t), t.numel())
+    return _GEMM_WS[key]
 
 
 def linear_fwd(x2d, w, bias=None, res=None, gelu_aux=None):

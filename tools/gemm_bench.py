@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Micro-benchmark of dvlp_gemm on the hot path's shapes (MI355X).  Usage: python tools/gemm_bench.py [--dtype bf16|fp32]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from demovlp_amd import ops  # noqa: E402
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--tokens", type=int, default=18496)
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = "cuda"
+    M = a.tokens
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows = []
+    for name, N, K in (("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)):
+        x = torch.randn(M, K, device=dev, generator=g).to(dt)
+        w = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(dt)
+        dy = torch.randn(M, N, device=dev, generator=g).to(dt)
+        bias = torch.zeros(N, device=dev)
+        fl = 2.0 * M * N * K
+        t = bench(lambda: ops.linear_fwd(x, w, bias))
+        rows.append((name + " fwd  (K,K)", M, N, K, t, fl / t / 1e12))
+        t = bench(lambda: ops.linear_bwd_input(dy, w))
+        rows.append((name + " dX   (K,R)", M, K, N, t, fl / t / 1e12))
+        t = bench(lambda: ops.linear_bwd_weight(dy, x))
+        rows.append((name + " dW   (R,R)", N, K, M, t, fl / t / 1e12))
+    for r in rows:
+        print("%-18s M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s" % (r[0], r[1], r[2], r[3], r[4] * 1e6, r[5]))
+
+
+if __name__ == "__main__":
+    main()
