@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
 // bf16 kernel
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int H_BM = 128, H_BN = 128, H_BK = 64;
-constexpr int H_LDK = H_BK + 8;    // form K tile: [128 rows][64 k] padded to 72 elements (144 B rows, 16-B aligned)
+constexpr int H_LDK = H_BK;        // form K tile: [128 rows][64 k], 128-B rows, 16-B chunk c stored at slot c ^ (row & 7):
+                                   // the 16 lanes of a ds_read_b128 group then hit 16 distinct 4-bank slots (conflict-free)
 constexpr int H_LDR = H_BM + 8;    // form R tile: [64 k][128 rows] padded to 136 elements (272 B rows, 16-B aligned)
 constexpr int H_TILE = (H_BM * H_LDK > H_BK * H_LDR ? H_BM * H_LDK : H_BK * H_LDR);   // elements per operand tile
 
@@ -313,7 +314,7 @@ __device__ __forceinline__ void h_store(bf16* __restrict__ S, const Stage4& s, i
     for (int i = 0; i < 4; ++i) {
         const int p = tid + 256 * i;
         if (FORM_R) { const int k = p >> 4, rq = (p & 15) * 8; *(uint4*)&S[k * H_LDR + rq] = s.v[i]; }
-        else        { const int row = p >> 3, kq = (p & 7) * 8; *(uint4*)&S[row * H_LDK + kq] = s.v[i]; }
+        else        { const int row = p >> 3, ch = p & 7; *(uint4*)&S[row * H_LDK + ((ch ^ (row & 7)) << 3)] = s.v[i]; }
     }
 }
 
@@ -324,7 +325,7 @@ template <bool FORM_R>
 __device__ __forceinline__ void h_frags(bf16x8 (&f)[4], const bf16* __restrict__ S, int rbase, int ks, int lane) {
     if (!FORM_R) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = *(const bf16x8*)&S[(rbase + 16 * i + (lane & 15)) * H_LDK + ks + 8 * (lane >> 4)];
+        for (int i = 0; i < 4; ++i) f[i] = *(const bf16x8*)&S[(rbase + 16 * i + (lane & 15)) * H_LDK + ((((ks >> 3) + (lane >> 4)) ^ (lane & 7)) << 3)];
     } else {
         // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of block row q, columns 4p..4p+3 of a
         // 4-row x 16-column block of 16-bit elements; lane i receives column i, rows 0..3.  Block rows = k, columns = r.
@@ -443,6 +444,167 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 kernel, LDS-DMA variant (K % 64 == 0, row counts of form-R operands % 8 == 0): the default on the hot path.
+// Tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), two stages, one barrier per K
+// tile.  An LDS-DMA instruction writes 1 KiB linearly (lane i -> base + 16 i), so tiles are UNPADDED and bank conflicts
+// are removed by permuting which global 16-byte chunk each lane fetches (swizzle on the source side, same involution on
+// the read side):
+//   form K tile [128 rows][64 k]  (128-B rows): chunk c of row r lives in slot c ^ (r & 7)          -> ds_read_b128
+//   form R tile [64 k][128 rows]  (256-B rows): chunk c of k-row k lives in slot c ^ (2 m(k)),
+//                                 m(k) = 4 ((k >> 3) & 1) + (k & 3)                                 -> ds_read_b64_tr_b16
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int G_TILE_B = 16384;    // bytes per operand tile per stage
+
+template <bool FORM_R>
+__device__ __forceinline__ void g_issue(char* lds_tile, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
+                                        int wid, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = wid * 4 + j;                      // 1-KiB piece (wave-uniform)
+        const bf16* src;
+        if (!FORM_R) {
+            const int rl = 8 * q + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+            int64_t gr = r0 + rl;
+            gr = gr > R - 1 ? R - 1 : gr;
+            src = X + gr * ld + k0 + c * 8;
+        } else {
+            const int kl = 4 * q + (lane >> 4), m = ((kl >> 3) & 1) * 4 + (kl & 3), c = (lane & 15) ^ (m << 1);
+            int64_t gr = r0 + c * 8;
+            gr = gr > R - 8 ? R - 8 : gr;
+            src = X + (k0 + kl) * ld + gr;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + q * 1024), 16, 0, 0);
+    }
+}
+
+// 8 transposing reads (4 fragments x lo/hi) from 4 per-fragment addresses; no wait (see g_wait8)
+__device__ __forceinline__ void g_tr8(bf16x4 (&lo)[4], bf16x4 (&hi)[4], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %9\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %4, %10\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %6, %11\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:1024"
+        : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+// retire every outstanding LDS read; naming the destinations makes every consumer depend on this statement
+__device__ __forceinline__ void g_wait8(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]) :: "memory");
+}
+
+template <bool A_R, bool B_R>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
+                                                             const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                             Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    int64_t tm_, tn_;
+    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
+    const int64_t m0 = tm_ * H_BM, n0 = tn_ * H_BN;
+    A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
+    if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
+    if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    const int64_t nk = (kend - kbeg) / H_BK;
+
+    // per-lane LDS read offsets inside a tile (stage / k-step offsets are added below)
+    const int g = lane >> 4, r = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!A_R) offA[i] = (unsigned)((wm + 16 * i + r) * 128);                                      // + slot*16 per k-step
+        else      offA[i] = (unsigned)((8 * g + qq) * 256 + ((((wm >> 3) + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
+        if (!B_R) offB[i] = (unsigned)((wn + 16 * i + r) * 128);
+        else      offB[i] = (unsigned)((8 * g + qq) * 256 + ((((wn >> 3) + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)smem_raw;
+
+    auto issue = [&](int64_t kt, int st) {
+        char* base = smem_raw + st * 2 * G_TILE_B;
+        g_issue<A_R>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane);
+        g_issue<B_R>(base + G_TILE_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane);
+    };
+    issue(0, 0);
+    __syncthreads();                                   // also drains the LDS-DMA (vmcnt(0))
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);       // stage cur^1 was last read before the previous barrier
+        const unsigned tA = lds0 + cur * 2 * G_TILE_B, tB = tA + G_TILE_B;
+        bf16x8 af[2][4], bfr[2][4];
+        bf16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (A_R) g_tr8(alo[s], ahi[s], tA + offA[0] + s * 8192, tA + offA[1] + s * 8192, tA + offA[2] + s * 8192, tA + offA[3] + s * 8192);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[s][i] = *(const bf16x8*)(smem_raw + cur * 2 * G_TILE_B + offA[i] + ((((4 * s + g) ^ (r & 7))) << 4));
+            }
+            if (B_R) g_tr8(blo[s], bhi[s], tB + offB[0] + s * 8192, tB + offB[1] + s * 8192, tB + offB[2] + s * 8192, tB + offB[3] + s * 8192);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bfr[s][i] = *(const bf16x8*)(smem_raw + cur * 2 * G_TILE_B + G_TILE_B + offB[i] + ((((4 * s + g) ^ (r & 7))) << 4));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (A_R) {
+                g_wait8(alo[s], ahi[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[s][i] = __builtin_shufflevector(alo[s][i], ahi[s][i], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if (B_R) {
+                g_wait8(blo[s], bhi[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bfr[s][i] = __builtin_shufflevector(blo[s][i], bhi[s][i], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    float* Ct = (float*)smem_raw + wid * (64 * 68);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Ct[(16 * i + 4 * (lane >> 4) + rr) * 68 + 16 * j + (lane & 15)] = acc[i][j][rr];
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+        const int64_t m = m0 + wm + row, n = n0 + wn + col;
+        const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (m < M && n < N) {
+            if (slab) {
+                float* dst = slab + ((int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M + m) * N + n;
+                if ((N & 3) == 0 && n + 7 < N) { *(float4*)dst = c0; *(float4*)(dst + 4) = c1; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) if (n + t < N) dst[t] = v[t];
+                }
+            } else epi_store8(e, C, ldc, m, n, v, N);
+        }
+    }
+}
+
 // second stage of a split-K GEMM: sum the S fp32 slabs of one output and apply the epilogue (8 columns per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int S, const float* __restrict__ slab, bf16* __restrict__ C,
                                                             int64_t ldc, Epi e) {
@@ -473,6 +635,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N
 // ------------------------------------------------------------------------------------------------------------------
 int g_dvlp_last_hip_error = 0;
 extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipError_t)g_dvlp_last_hip_error); }
+
+// A/B switch between the LDS-DMA kernel (default) and the register-staged one (tools/gemm_bench.py --variant)
+static bool g_use_glds = true;
+extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
 
 // caller-provided scratch for split-K slabs (dvlp_set_workspace); nullptr disables splitting
 static float* g_ws = nullptr;
@@ -560,7 +726,12 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
         hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
-#define LAUNCH_BF16(AR, BR) do { if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
+#define LAUNCH_GLDS_(AR, BR) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
+        const bool dma = !safe && K % H_BK == 0 && g_use_glds;
+#define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         if (!transA && !transB) LAUNCH_BF16(false, false);
         else if (!transA && transB) LAUNCH_BF16(false, true);
         else if (transA && transB) LAUNCH_BF16(true, true);
@@ -569,6 +740,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M * cdiv(N, 8), 256), (unsigned)batch), dim3(256), 0, st, M, N, (int)S,
                                (const float*)slab, (bf16*)C, ldc, e);
 #undef LAUNCH_BF16_
+#undef LAUNCH_GLDS_
 #undef LAUNCH_BF16
     } else {
         return DVLP_ERR_DTYPE;

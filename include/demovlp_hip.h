@@ -41,6 +41,8 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
                       const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
                       void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
                       int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
+/* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
+int dvlp_gemm_variant(int use_lds_dma);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */
 int dvlp_set_workspace(void* ptr, int64_t bytes);
 /* per-launch HIP-event timing of the GEMM kernels (bench.py roofline figure) */
