@@ -145,6 +145,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, _, _ = train_step(model, loss_fn, opt, data, reducer)
+    host_elapsed = time.perf_counter() - t0          # time for the host to ENQUEUE the steps (launch-bound if ~= elapsed)
     sync()
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
@@ -170,6 +171,7 @@ def main():
                                    "region features + random 100-token captions, per-GPU batch %d" % (F, R, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "optimizer": "fused HF-AdamW",
                        "final_loss": round(final_loss, 4)},
+            "host_enqueue_ms_per_step": round(1e3 * host_elapsed / a.steps, 3),
             "step_model_tflops": round(value * fpp / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * fpp / 1e12 / (peak * world), 4),
         }

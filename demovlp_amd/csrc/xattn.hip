@@ -263,17 +263,28 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
         }
     }
     __syncthreads();
-    // A = S / rn with rn = |S_row| + eps:  dS = dA/rn - S <dA,S>_row / (rn^2 (rn - eps)); same along columns; then LeakyReLU'
+    // A = S / rn with rn = |S_row| + eps:  dS = dA/rn - S <dA,S>_row / (rn^2 (rn - eps)); same along columns; then LeakyReLU'.
+    // D1 is stored [w][g] (g contiguous) but dS is written [g][w]: go through a 64-row LDS transpose tile so that every
+    // global access of this pass is contiguous (reading D1 column-wise cost one cache line per element).
     T* S = (T*)a.S;
-    for (int g = wid; g < a.G; g += nw) {
-        const float r = rn[g], cr = rowdot[g] / (r * r * fmaxf(r - 1e-8f, 1e-30f));
-        T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
-        for (int w = lane; w < a.W; w += 64) {
-            const float c = cn[w], cc = coldot[w] / (c * c * fmaxf(c - 1e-8f, 1e-30f));
-            const float sv = Ssm[g * a.Wq + w];
-            const float ds = to_f(D1[(int64_t)w * a.Gp + g]) + to_f(D2[(int64_t)g * a.Wp + w]) - sv * (cr + cc);
-            row[w] = from_f<T>(sv > 0.f ? ds : 0.1f * ds);
+    float* tile = coldot + a.W;                 // [64][Wq]
+    for (int g0 = 0; g0 < a.G; g0 += 64) {
+        const int ng = a.G - g0 < 64 ? a.G - g0 : 64;
+        for (int w = wid; w < a.W; w += nw)
+            if (lane < ng) tile[lane * a.Wq + w] = to_f(D1[(int64_t)w * a.Gp + g0 + lane]);
+        __syncthreads();
+        for (int gl = wid; gl < ng; gl += nw) {
+            const int g = g0 + gl;
+            const float r = rn[g], cr = rowdot[g] / (r * r * fmaxf(r - 1e-8f, 1e-30f));
+            T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
+            for (int w = lane; w < a.W; w += 64) {
+                const float c = cn[w], cc = coldot[w] / (c * c * fmaxf(c - 1e-8f, 1e-30f));
+                const float sv = Ssm[g * a.Wq + w];
+                const float ds = tile[gl * a.Wq + w] + to_f(D2[(int64_t)g * a.Wp + w]) - sv * (cr + cc);
+                row[w] = from_f<T>(sv > 0.f ? ds : 0.1f * ds);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(256) void xprep_bwd_kernel(int64_t outer, int64_t i
 constexpr int XMAX_NKG = 6, XMAX_NKW = 2;    // G <= 384, W <= 128 (the S_ij tile must fit the 160 KiB LDS anyway)
 static size_t pair_lds(int64_t G, int64_t W, int bwd) {
     const int64_t Wq = W | 1;
-    return (size_t)(G * Wq + G + W + 8 * W + (bwd ? G + W : 0)) * sizeof(float);
+    return (size_t)(G * Wq + G + W + 8 * W + (bwd ? G + W + 64 * Wq : 0)) * sizeof(float);
 }
 
 // dispatch the per-pair kernels on the compile-time chunk counts NKG = ceil(G/64), NKW = ceil(W/64)
