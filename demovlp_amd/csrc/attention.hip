@@ -239,10 +239,20 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     float* S = sm; float* DP = S + N; float* red = DP + N;   // red: [4][64] + scalars
     const float qv = to_f(q[brow0 * a.ld + h * HD + lane]) * a.scale;
     const float dov = to_f(dout[brow0 * a.ldo + h * HD + lane]);
-    for (int j = wid; j < N; j += 4) {
-        const float kv = to_f(k[(brow0 + j) * a.ld + h * HD + lane]), vv = to_f(v[(brow0 + j) * a.ld + h * HD + lane]);
-        const float s = wave_sum(qv * kv), dp = wave_sum(dov * vv);
-        if (lane == 0) { S[j] = s + a.addmask[brow0 + j]; DP[j] = dp; }
+    // four keys per wave per step: all loads of a step are issued before the first reduction (the loop is latency-bound)
+    for (int j0 = wid * 4; j0 < N; j0 += 16) {
+        float kv[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u < N ? j0 + u : N - 1;
+            kv[u] = to_f(k[(brow0 + j) * a.ld + h * HD + lane]);
+            vv[u] = to_f(v[(brow0 + j) * a.ld + h * HD + lane]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float s = wave_sum(qv * kv[u]), dp = wave_sum(dov * vv[u]);
+            if (lane == 0 && j0 + u < N) { S[j0 + u] = s + a.addmask[brow0 + j0 + u]; DP[j0 + u] = dp; }
+        }
     }
     __syncthreads();
     // every wave redundantly reduces the (small) score vector
@@ -254,18 +264,30 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     l = wave_sum(l); pd = wave_sum(pd);
     const float inv = 1.f / l, Dsum = pd * inv;
     float dqa = 0.f;
-    for (int j = wid; j < N; j += 4) {
-        const float p = expf(S[j] - m) * inv, ds = p * (DP[j] - Dsum);
-        const int64_t off = (brow0 + j) * a.ld + h * HD + lane, offd = (brow0 + j) * a.ldd + h * HD + lane;
-        dqa += ds * to_f(k[off]);
-        float gk = ds * qv, gv = p * dov;
-        if (j == 0) {
-            const float* w = a.ws + (((int64_t)b * a.H + h) * a.F) * 2 * HD;
-            for (int f = 0; f < a.F; ++f) { gk += w[f * 2 * HD + lane]; gv += w[f * 2 * HD + HD + lane]; }
-        } else {
-            gk += to_f(dk[offd]); gv += to_f(dv[offd]);
+    for (int j0 = wid * 4; j0 < N; j0 += 16) {
+        float kk[4], gk0[4], gv0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u < N ? j0 + u : N - 1;
+            kk[u] = to_f(k[(brow0 + j) * a.ld + h * HD + lane]);
+            if (j == 0) { gk0[u] = 0.f; gv0[u] = 0.f; }
+            else { gk0[u] = to_f(dk[(brow0 + j) * a.ldd + h * HD + lane]); gv0[u] = to_f(dv[(brow0 + j) * a.ldd + h * HD + lane]); }
         }
-        dk[offd] = from_f<T>(gk); dv[offd] = from_f<T>(gv);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            if (j < N) {
+                const float p = expf(S[j] - m) * inv, ds = p * (DP[j] - Dsum);
+                const int64_t offd = (brow0 + j) * a.ldd + h * HD + lane;
+                dqa += ds * kk[u];
+                float gk = ds * qv + gk0[u], gv = p * dov + gv0[u];
+                if (j == 0) {
+                    const float* w = a.ws + (((int64_t)b * a.H + h) * a.F) * 2 * HD;
+                    for (int f = 0; f < a.F; ++f) { gk += w[f * 2 * HD + lane]; gv += w[f * 2 * HD + HD + lane]; }
+                }
+                dk[offd] = from_f<T>(gk); dv[offd] = from_f<T>(gv);
+            }
+        }
     }
     red[wid * 64 + lane] = dqa;
     __syncthreads();
@@ -385,13 +407,13 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r]; m = fmaxf(m, st[kt][qt][r]); }
-        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = col4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st[kt][qt][r] = expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
-        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        sum = col4_sum(sum);
         const float inv = 1.f / sum;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -475,20 +497,20 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r]; m = fmaxf(m, st[kt][qt][r]); }
-            m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = col4_max(m);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { st[kt][qt][r] = expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
-            sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            sum = col4_sum(sum);
             const float inv = 1.f / sum;
             float D = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { st[kt][qt][r] *= inv; D += st[kt][qt][r] * dp[kt][qt][r]; }
-            D += __shfl_xor(D, 16, 64); D += __shfl_xor(D, 32, 64);
+            D = col4_sum(D);
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -554,19 +576,16 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
                 float m = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = s2[qt][kt][r] * a.scale + mk[kt]; m = fmaxf(m, s2[qt][kt][r]); }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                m = row16_max(m);
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = expf(s2[qt][kt][r] - m); sum += s2[qt][kt][r]; }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                sum = row16_sum(sum);
                 const float inv = qok ? 1.f / sum : 0.f;                    // padded query rows contribute nothing
                 float D = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] *= inv; D += s2[qt][kt][r] * dp[qt][kt][r]; }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) D += __shfl_xor(D, o, 64);
+                D = row16_sum(D);
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) dp[qt][kt][r] = s2[qt][kt][r] * (dp[qt][kt][r] - D);   // dS
             }
@@ -680,20 +699,20 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
                 st[kt][r] = st[kt][r] * a.scale + (tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY);
                 m = fmaxf(m, st[kt][r]);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = col4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st[kt][r] = expf(st[kt][r] - m); sum += st[kt][r]; }
-        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        sum = col4_sum(sum);
         const float inv = 1.f / sum;
         float D = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st[kt][r] *= inv; D += st[kt][r] * dp[kt][r]; }
-        D += __shfl_xor(D, 16, 64); D += __shfl_xor(D, 32, 64);
+        D = col4_sum(D);
         if (g == 0) { float* sp = stats + (16 * qt + c) * 3; sp[0] = m; sp[1] = inv; sp[2] = D; }
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)

@@ -101,6 +101,19 @@ struct PairArgs {
 
 constexpr int XT = 1024;     // threads per pair workgroup: 16 waves share one S_ij tile (the tile caps residency at 1 block/CU)
 
+// all-reduce inside each 32-lane half of the wave (two softmax rows per wave in the text->image sweep)
+__device__ __forceinline__ float half_sum(float v) {
+    v = row16_sum(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float v) {
+    v = row16_max(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Stage S_ij in LDS and compute the RECIPROCAL row / column norms (1 / (|.| + 1e-8), loss.py:238 for both directions)
 template <typename T>
 __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, float* Ssm, float* rn, float* cn, float* cpart /*[8][W]*/) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -110,10 +123,9 @@ __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, flo
         float q = 0.f;
         for (int w = lane; w < a.W; w += 64) { const float v = to_f(row[w]); Ssm[g * a.Wq + w] = v; q += v * v; }
         q = wave_sum(q);
-        if (lane == 0) rn[g] = sqrtf(q) + 1e-8f;                       // l2norm over words (loss.py:238)
+        if (lane == 0) rn[g] = 1.f / (sqrtf(q) + 1e-8f);
     }
     __syncthreads();
-    // column norms: 8 row-slices per column, then combine
     {
         const int w = threadIdx.x & 127, part = threadIdx.x >> 7;
         if (w < a.W) {
@@ -127,26 +139,29 @@ __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, flo
         float q = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) q += cpart[k * a.W + w];
-        cn[w] = sqrtf(q) + 1e-8f;                                       // l2norm over regions (second call of :238)
+        cn[w] = 1.f / (sqrtf(q) + 1e-8f);
     }
     __syncthreads();
 }
 
-// softmax over n entries held as e[k] on lane (idx = lane + 64k); returns P (pre-gate) in e, P' in pp; s = sum of gated P
-template <int NK>
-__device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], int n, int lane, int gate, float& s_out) {
+// softmax over n entries spread over a lane group (FULL = 64 lanes, else a 32-lane half); e[k] is the entry of lane-slot
+// idx = lid + STRIDE*k.  Returns P (pre-gate) in e, P' (gated, renormalised) in pp, s = sum of gated P.
+template <int NK, bool FULL>
+__device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], int n, int lid, int gate, float& s_out) {
+    constexpr int STRIDE = FULL ? 64 : 32;
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) m = fmaxf(m, lane + 64 * k < n ? e[k] : -INFINITY);
-    m = wave_max(m);
+    for (int k = 0; k < NK; ++k) m = fmaxf(m, lid + STRIDE * k < n ? e[k] : -INFINITY);
+    m = FULL ? wave_max(m) : half_max(m);
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) { e[k] = lane + 64 * k < n ? expf(e[k] - m) : 0.f; sum += e[k]; }
-    const float inv = 1.f / wave_sum(sum);
+    for (int k = 0; k < NK; ++k) { e[k] = lid + STRIDE * k < n ? __expf(e[k] - m) : 0.f; sum += e[k]; }
+    sum = FULL ? wave_sum(sum) : half_sum(sum);
+    const float inv = 1.f / sum;
     float psum = 0.f;
 #pragma unroll
     for (int k = 0; k < NK; ++k) { e[k] = e[k] * inv; psum += e[k]; }
-    psum = wave_sum(psum);
+    psum = FULL ? wave_sum(psum) : half_sum(psum);
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -154,17 +169,19 @@ __device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], i
         pp[k] = h * e[k];
         s += pp[k];
     }
-    s = wave_sum(s);
+    s = FULL ? wave_sum(s) : half_sum(s);
     const float is = 1.f / s;
 #pragma unroll
     for (int k = 0; k < NK; ++k) pp[k] = pp[k] * is;
     s_out = s;
 }
 
+// NKG = ceil(Gp / 64) entries per lane in the image->text sweep (one word per wave);
+// NKW = ceil(Wp / 32) entries per lane in the text->image sweep (one region per 32-lane half, two regions per wave)
 template <typename T, int NKG, int NKW>
 __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, half = lane >> 5, hl = lane & 31;
     const int j = blockIdx.x, i = blockIdx.y;
     float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* cpart = cn + a.W;
     pair_load_S<T>(a, i, j, Ssm, rn, cn, cpart);
@@ -173,12 +190,15 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
     const float* mimg = a.mimg + (int64_t)i * a.G;
     const float* mcap = a.mcap + (int64_t)j * a.W;
     // image -> text: for each word, softmax over regions (the caption-mask term is constant along this axis)
+    float mi[NKG], ri[NKG];
+#pragma unroll
+    for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; mi[k] = g < a.G ? mimg[g] : 0.f; ri[k] = g < a.G ? rn[g] : 0.f; }
     for (int w = wid; w < a.Wp; w += nw) {
         float e[NKG], pp[NKG], s;
         if (w < a.W) {
 #pragma unroll
-            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
-            focal_softmax<NKG>(e, pp, a.G, lane, a.gate, s);
+            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] * ri[k] + mi[k]) : 0.f; }
+            focal_softmax<NKG, true>(e, pp, a.G, lane, a.gate, s);
         } else {
 #pragma unroll
             for (int k = 0; k < NKG; ++k) pp[k] = 0.f;
@@ -187,13 +207,21 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
         for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(g < a.G ? pp[k] : 0.f); }
     }
     // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
-    for (int g = wid; g < a.G; g += nw) {
+    float mc[NKW], ci[NKW];
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; }
+    for (int g0 = 2 * wid; g0 < a.G; g0 += 2 * nw) {
+        const int g = g0 + half;
+        const bool ok = g < a.G;
+        const int gc = ok ? g : a.G - 1;
         float e[NKW], pp[NKW], s;
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
-        focal_softmax<NKW>(e, pp, a.W, lane, a.gate, s);
+        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; e[k] = w < a.W ? a.lam * (Ssm[gc * a.Wq + w] * ci[k] + mc[k]) : 0.f; }
+        focal_softmax<NKW, false>(e, pp, a.W, hl, a.gate, s);
+        if (ok) {
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+            for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+        }
     }
 }
 
@@ -201,73 +229,100 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
 template <typename T, int NKG, int NKW>
 __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, half = lane >> 5, hl = lane & 31;
     const int j = blockIdx.x, i = blockIdx.y;
     float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* cpart = cn + a.W;
     float* rowdot = cpart + 8 * a.W; float* coldot = rowdot + a.G;
-    for (int t = threadIdx.x; t < a.G; t += blockDim.x) rowdot[t] = 0.f;
-    for (int t = threadIdx.x; t < a.W; t += blockDim.x) coldot[t] = 0.f;
+    float* tile = coldot + a.W;                 // [64][Wq] transpose tile of the last pass; before that: per-wave partial dots
     pair_load_S<T>(a, i, j, Ssm, rn, cn, cpart);
-    T* D1 = (T*)a.dP1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;     // in: dP1, out: dA / rn
-    T* D2 = (T*)a.dP2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;      // in: dP2, out: dA2 / cn
+    T* D1 = (T*)a.dP1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;     // in: dP1, out: dA * rn^-1
+    T* D2 = (T*)a.dP2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;      // in: dP2, out: dA2 * cn^-1
     const float* mimg = a.mimg + (int64_t)i * a.G;
     const float* mcap = a.mcap + (int64_t)j * a.W;
-    for (int w = wid; w < a.W; w += nw) {
-        float e[NKG], pp[NKG], s;
+    float* rpart = tile;                        // [nw][G]   per-wave partial <dA, S> over the words the wave owned
+    float* qpart = tile + nw * a.G;             // [2 nw][Wp32] per-half partial <dA2, S> over the regions the half owned
+    {
+        float mi[NKG], ri[NKG], rd[NKG];
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] / rn[g] + mimg[g]) : 0.f; }
-        focal_softmax<NKG>(e, pp, a.G, lane, a.gate, s);
-        float dpp[NKG], d1 = 0.f;
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; mi[k] = g < a.G ? mimg[g] : 0.f; ri[k] = g < a.G ? rn[g] : 0.f; rd[k] = 0.f; }
+        for (int w = wid; w < a.W; w += nw) {
+            float e[NKG], pp[NKG], sv[NKG], s;
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; dpp[k] = g < a.G ? to_f(D1[(int64_t)w * a.Gp + g]) : 0.f; d1 += dpp[k] * pp[k]; }
-        d1 = wave_sum(d1);
-        float d2 = 0.f;
+            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; sv[k] = g < a.G ? Ssm[g * a.Wq + w] : 0.f; e[k] = a.lam * (sv[k] * ri[k] + mi[k]); }
+            focal_softmax<NKG, true>(e, pp, a.G, lane, a.gate, s);
+            float dpp[NKG], d1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) {
-            // P' = T / s, T = H P  ->  dP = H (dP' - <dP', P'>) / s   (H is a constant gate; pp > 0 <=> H = 1)
-            dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f;
-            d2 += dpp[k] * e[k];
-        }
-        d2 = wave_sum(d2);
+            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; dpp[k] = g < a.G ? to_f(D1[(int64_t)w * a.Gp + g]) : 0.f; d1 += dpp[k] * pp[k]; }
+            d1 = wave_sum(d1);
+            const float is = 1.f / s;
+            float d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) {
-            const int g = lane + 64 * k;
-            if (g < a.G) {
+            for (int k = 0; k < NKG; ++k) {
+                // P' = T / s, T = H P  ->  dP = H (dP' - <dP', P'>) / s   (H is a constant gate; pp > 0 <=> H = 1)
+                dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) * is : 0.f;
+                d2 += dpp[k] * e[k];
+            }
+            d2 = wave_sum(d2);
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) {
+                const int g = lane + 64 * k;
                 const float dA = a.lam * e[k] * (dpp[k] - d2);           // softmax backward, times lambda
-                D1[(int64_t)w * a.Gp + g] = from_f<T>(dA / rn[g]);
-                atomicAdd(&rowdot[g], dA * Ssm[g * a.Wq + w]);
+                if (g < a.G) D1[(int64_t)w * a.Gp + g] = from_f<T>(dA * ri[k]);
+                rd[k] += dA * sv[k];
             }
         }
+#pragma unroll
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.G) rpart[wid * a.G + g] = rd[k]; }
     }
-    for (int g = wid; g < a.G; g += nw) {
-        float e[NKW], pp[NKW], s;
+    {
+        const int W32 = 32 * NKW;
+        float mc[NKW], ci[NKW], cd[NKW];
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; e[k] = w < a.W ? a.lam * (Ssm[g * a.Wq + w] / cn[w] + mcap[w]) : 0.f; }
-        focal_softmax<NKW>(e, pp, a.W, lane, a.gate, s);
-        float dpp[NKW], d1 = 0.f;
+        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; cd[k] = 0.f; }
+        for (int g0 = 2 * wid; g0 < a.G; g0 += 2 * nw) {
+            const int g = g0 + half;
+            const bool ok = g < a.G;
+            const int gc = ok ? g : a.G - 1;
+            float e[NKW], pp[NKW], sv[NKW], s;
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = lane + 64 * k; dpp[k] = w < a.W ? to_f(D2[(int64_t)g * a.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
-        d1 = wave_sum(d1);
-        float d2 = 0.f;
+            for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = a.lam * (sv[k] * ci[k] + mc[k]); }
+            focal_softmax<NKW, false>(e, pp, a.W, hl, a.gate, s);
+            float dpp[NKW], d1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) / s : 0.f; d2 += dpp[k] * e[k]; }
-        d2 = wave_sum(d2);
+            for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; dpp[k] = w < a.W ? to_f(D2[(int64_t)gc * a.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
+            d1 = half_sum(d1);
+            const float is = 1.f / s;
+            float d2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) {
-            const int w = lane + 64 * k;
-            if (w < a.W) {
-                const float dA = a.lam * e[k] * (dpp[k] - d2);
-                D2[(int64_t)g * a.Wp + w] = from_f<T>(dA / cn[w]);
-                atomicAdd(&coldot[w], dA * Ssm[g * a.Wq + w]);
+            for (int k = 0; k < NKW; ++k) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) * is : 0.f; d2 += dpp[k] * e[k]; }
+            d2 = half_sum(d2);
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) {
+                const int w = hl + 32 * k;
+                const float dA = ok ? a.lam * e[k] * (dpp[k] - d2) : 0.f;
+                if (ok && w < a.W) D2[(int64_t)g * a.Wp + w] = from_f<T>(dA * ci[k]);
+                cd[k] += dA * sv[k];
             }
         }
+#pragma unroll
+        for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + hl + 32 * k] = cd[k];
     }
     __syncthreads();
-    // A = S / rn with rn = |S_row| + eps:  dS = dA/rn - S <dA,S>_row / (rn^2 (rn - eps)); same along columns; then LeakyReLU'.
+    for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < nw; ++k) t += rpart[k * a.G + g];
+        rowdot[g] = t;
+    }
+    for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < 2 * nw; ++k) t += qpart[k * 32 * NKW + w];
+        coldot[w] = t;
+    }
+    __syncthreads();
+    // A = S r with r = 1 / (|S_row| + eps):  dS = dA r - S <dA,S>_row r^2 / (1/r - eps); same along columns; then LeakyReLU'.
     // D1 is stored [w][g] (g contiguous) but dS is written [g][w]: go through a 64-row LDS transpose tile so that every
-    // global access of this pass is contiguous (reading D1 column-wise cost one cache line per element).
+    // global access of this pass is contiguous.
     T* S = (T*)a.S;
-    float* tile = coldot + a.W;                 // [64][Wq]
     for (int g0 = 0; g0 < a.G; g0 += 64) {
         const int ng = a.G - g0 < 64 ? a.G - g0 : 64;
         for (int w = wid; w < a.W; w += nw)
@@ -275,10 +330,10 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
         __syncthreads();
         for (int gl = wid; gl < ng; gl += nw) {
             const int g = g0 + gl;
-            const float r = rn[g], cr = rowdot[g] / (r * r * fmaxf(r - 1e-8f, 1e-30f));
+            const float r = rn[g], cr = rowdot[g] * r * r / fmaxf(1.f / r - 1e-8f, 1e-30f);
             T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
             for (int w = lane; w < a.W; w += 64) {
-                const float c = cn[w], cc = coldot[w] / (c * c * fmaxf(c - 1e-8f, 1e-30f));
+                const float c = cn[w], cc = coldot[w] * c * c / fmaxf(1.f / c - 1e-8f, 1e-30f);
                 const float sv = Ssm[g * a.Wq + w];
                 const float ds = tile[gl * a.Wq + w] + to_f(D2[(int64_t)g * a.Wp + w]) - sv * (cr + cc);
                 row[w] = from_f<T>(sv > 0.f ? ds : 0.1f * ds);
@@ -421,10 +476,11 @@ __global__ __launch_bounds__(256) void xprep_bwd_kernel(int64_t outer, int64_t i
 // ------------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int XMAX_NKG = 6, XMAX_NKW = 2;    // G <= 384, W <= 128 (the S_ij tile must fit the 160 KiB LDS anyway)
+constexpr int XMAX_NKG = 6, XMAX_NKW = 4;    // G <= 384, W <= 128 (the S_ij tile must fit the 160 KiB LDS anyway)
 static size_t pair_lds(int64_t G, int64_t W, int bwd) {
     const int64_t Wq = W | 1;
-    return (size_t)(G * Wq + G + W + 8 * W + (bwd ? G + W + 64 * Wq : 0)) * sizeof(float);
+    const int64_t tile = 64 * Wq > 16 * G + 32 * 32 * cdiv(rup(W, 8), 32) ? 64 * Wq : 16 * G + 32 * 32 * cdiv(rup(W, 8), 32);
+    return (size_t)(G * Wq + G + W + 8 * W + (bwd ? G + W + tile : 0)) * sizeof(float);
 }
 
 // dispatch the per-pair kernels on the compile-time chunk counts NKG = ceil(G/64), NKW = ceil(W/64)
@@ -434,7 +490,7 @@ static void launch_pair_w(bool bwd, int nkw, dim3 grid, size_t lds, hipStream_t 
         auto kf = xsoftmax_fwd_kernel<T, NKG, NKW_>; auto kb = xsoftmax_bwd_kernel<T, NKG, NKW_>; \
         (void)hipFuncSetAttribute((const void*)(bwd ? kb : kf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (bwd) hipLaunchKernelGGL(kb, grid, dim3(XT), lds, st, pa); else hipLaunchKernelGGL(kf, grid, dim3(XT), lds, st, pa); } while (0)
-    if (nkw == 1) XLAUNCH(1); else XLAUNCH(2);
+    if (nkw == 1) XLAUNCH(1); else if (nkw == 2) XLAUNCH(2); else if (nkw == 3) XLAUNCH(3); else XLAUNCH(4);
 #undef XLAUNCH
 }
 template <typename T>
@@ -454,7 +510,7 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
                               const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd,
                               void* stream) {
     dvlp_clear_status();
-    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 64 * XMAX_NKW) return DVLP_ERR_SHAPE;
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
     if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;      // long-video (G > ~380) tiling: not in round 1
     hipStream_t st = (hipStream_t)stream;
@@ -482,7 +538,7 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.lam = lam; pa.gate = gate;
     {
         const size_t lds = pair_lds(G, W, 0);
-        const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 64);
+        const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 32);
         if (dtype == DVLP_F32) launch_pair<float>(false, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
         else launch_pair<bf16>(false, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
     }
@@ -504,7 +560,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
                               const float* mimg, const float* mcap, float lam, int gate, const float* dscores, void* workspace,
                               void* dC, void* dQ, void* stream) {
     dvlp_clear_status();
-    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 64 * XMAX_NKW) return DVLP_ERR_SHAPE;
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
     if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -533,7 +589,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.lam = lam; pa.gate = gate;
     {
         const size_t lds = pair_lds(G, W, 1);
-        const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 64);
+        const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 32);
         if (dtype == DVLP_F32) launch_pair<float>(true, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);      // S <- dS_raw
         else launch_pair<bf16>(true, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
     }
