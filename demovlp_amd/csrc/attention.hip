@@ -239,17 +239,18 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     float* S = sm; float* DP = S + N; float* red = DP + N;   // red: [4][64] + scalars
     const float qv = to_f(q[brow0 * a.ld + h * HD + lane]) * a.scale;
     const float dov = to_f(dout[brow0 * a.ldo + h * HD + lane]);
-    // four keys per wave per step: all loads of a step are issued before the first reduction (the loop is latency-bound)
-    for (int j0 = wid * 4; j0 < N; j0 += 16) {
-        float kv[4], vv[4];
+    constexpr int CK = 8;
+    // CK keys per wave per step: all loads of a step are issued before the first reduction (the loop is latency-bound)
+    for (int j0 = wid * CK; j0 < N; j0 += 4 * CK) {
+        float kv[CK], vv[CK];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CK; ++u) {
             const int j = j0 + u < N ? j0 + u : N - 1;
             kv[u] = to_f(k[(brow0 + j) * a.ld + h * HD + lane]);
             vv[u] = to_f(v[(brow0 + j) * a.ld + h * HD + lane]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CK; ++u) {
             const float s = wave_sum(qv * kv[u]), dp = wave_sum(dov * vv[u]);
             if (lane == 0 && j0 + u < N) { S[j0 + u] = s + a.addmask[brow0 + j0 + u]; DP[j0 + u] = dp; }
         }
@@ -264,17 +265,17 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     l = wave_sum(l); pd = wave_sum(pd);
     const float inv = 1.f / l, Dsum = pd * inv;
     float dqa = 0.f;
-    for (int j0 = wid * 4; j0 < N; j0 += 16) {
-        float kk[4], gk0[4], gv0[4];
+    for (int j0 = wid * CK; j0 < N; j0 += 4 * CK) {
+        float kk[CK], gk0[CK], gv0[CK];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CK; ++u) {
             const int j = j0 + u < N ? j0 + u : N - 1;
             kk[u] = to_f(k[(brow0 + j) * a.ld + h * HD + lane]);
             if (j == 0) { gk0[u] = 0.f; gv0[u] = 0.f; }
             else { gk0[u] = to_f(dk[(brow0 + j) * a.ldd + h * HD + lane]); gv0[u] = to_f(dv[(brow0 + j) * a.ldd + h * HD + lane]); }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CK; ++u) {
             const int j = j0 + u;
             if (j < N) {
                 const float p = expf(S[j] - m) * inv, ds = p * (DP[j] - Dsum);
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
 }
 
 // backward, space mode: one wave per (b, h, frame).  Layout 1 (S^T) -> dQ; layout 2 (S) -> dK, dV.  P is recomputed.
-template <int NQT, int NKT>
+template <int NQT, int NKT, int PART>
 __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int items) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     constexpr int NQTP = (NQT + 1) & ~1, NKTP = (NKT + 1) & ~1, TROWS = 16 * (NQTP > NKTP ? NQTP : NKTP);
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
     bf16* Ts = (bf16*)smraw + wid * (TROWS * VLD);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // ---------------- layout 1: keys on (g, r), queries on lane&15 -> dQ ----------------
-    {
+    if (PART == 0) {
         bf16x8 qf[NQT][2], gf[NQT][2], kf[NKT][2], vf[NKT][2];
         load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
         load_row_frags<NQT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
             }
     }
     // ---------------- layout 2: queries on (g, r), keys on lane&15 -> dV, dK ----------------
-    {
+    if (PART == 1) {
         bf16x8 qf[NQT][2], gf[NQT][2], kf[NKT][2], vf[NKT][2];
         load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
         load_row_frags<NQT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
@@ -885,7 +886,8 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
             const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
             const int items = (int)(B * H * F);
 #define MBWD(NQT_, NKT_) do { const int tr_ = 16 * ((((NQT_ + 1) & ~1) > ((NKT_ + 1) & ~1)) ? ((NQT_ + 1) & ~1) : ((NKT_ + 1) & ~1)); \
-            hipLaunchKernelGGL((mattn_bwd_space_kernel<NQT_, NKT_>), dim3((unsigned)cdiv(items, 4)), block, (size_t)4 * tr_ * VLD * sizeof(bf16), st, a, items); done = true; } while (0)
+            hipLaunchKernelGGL((mattn_bwd_space_kernel<NQT_, NKT_, 0>), dim3((unsigned)cdiv(items, 4)), block, (size_t)4 * tr_ * VLD * sizeof(bf16), st, a, items); \
+            hipLaunchKernelGGL((mattn_bwd_space_kernel<NQT_, NKT_, 1>), dim3((unsigned)cdiv(items, 4)), block, (size_t)4 * tr_ * VLD * sizeof(bf16), st, a, items); done = true; } while (0)
             if (nqt == 3 && nkt == 3) MBWD(3, 3);
             else if (nqt == 2 && nkt == 2) MBWD(2, 2);
             else if (nqt == 1 && nkt == 1) MBWD(1, 1);

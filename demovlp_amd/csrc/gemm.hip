@@ -638,6 +638,8 @@ extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipE
 
 // A/B switch between the LDS-DMA kernel (default) and the register-staged one (tools/gemm_bench.py --variant)
 static bool g_use_glds = true;
+static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
+extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
 extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
 
 // caller-provided scratch for split-K slabs (dvlp_set_workspace); nullptr disables splitting
@@ -710,7 +712,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         int64_t S = 1;
         const int64_t tiles = ntm * ntn * batch;
         if (g_ws && tiles < 384 && K >= 1024) {
-            S = (768 + tiles - 1) / tiles;
+            S = (g_splitk_target + tiles - 1) / tiles;
             if (S > K / 256) S = K / 256;
             if (S > 32) S = 32;
             while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;

@@ -129,10 +129,11 @@ class ObjectPrologueFn(torch.autograd.Function):
         dWo = _wgrad(dtok, feat, Wo)
         dbo = _bgrad(dtok, bo)
         dbp = _into(bp, dbo.clone())                      # same sum: both biases are added to every region token
-        dWp = _into(Wp, ops.box_wgrad(dtok, box))
+        dWp = ops.box_wgrad(dtok, box, out=_grad_buf(Wp))
         # temporal[f] = sum over (b, r) of dtok[b, f, r, :]
-        dtemp = ops.colsum_grouped(dtok, B * R, 768, 768, R, F * R * 768, F, R * 768)
-        dtemp = _into(temporal, dtemp.reshape(1, F, 768))
+        gt = _grad_buf(temporal) if temporal.shape[1] == F else None
+        dtemp = ops.colsum_grouped(dtok, B * R, 768, 768, R, F * R * 768, F, R * 768, out=gt)
+        dtemp = dtemp if gt is not None else dtemp.reshape(1, F, 768)
         dcls_row = ops.colsum_grouped(dx, B, 768, N * 768, B, 0, 1, 0).reshape(768)     # sum_b dx[b, 0, :]
         dcls = _into(cls, dcls_row.reshape(1, 1, 768))
         dpos = torch.zeros_like(pos_embed)
@@ -175,7 +176,7 @@ class VitBlockFn(torch.autograd.Function):
         df1b = _bgrad(dpre, f1b)
         df1w = _wgrad(dpre, h2, f1w)
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
-        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w.detach(), m2, r2, dres=dy2)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w.detach(), m2, r2, dres=dy2, out_gamma=_grad_buf(n2w), out_beta=_grad_buf(n2b))
         dpb = _bgrad(dx1, pb)
         dpw = _wgrad(dx1, att, pw)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
@@ -183,9 +184,8 @@ class VitBlockFn(torch.autograd.Function):
         dqkvb = _bgrad(dqkv, qkvb)
         dqkvw = _wgrad(dqkv, h1, qkvw)
         dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
-        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2, n1w.detach(), m1, r1, dres=dx1)
-        return (dx.reshape(B, N, -1), None, _into(n1w, dn1w), _into(n1b, dn1b), dqkvw, dqkvb, dpw, dpb, _into(n2w, dn2w),
-                _into(n2b, dn2b), df1w, df1b, df2w, df2b, None, None)
+        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2, n1w.detach(), m1, r1, dres=dx1, out_gamma=_grad_buf(n1w), out_beta=_grad_buf(n1b))
+        return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -207,7 +207,7 @@ class TextEmbedFn(torch.autograd.Function):
         word, pos, lnw, lnb = ctx.params
         B, L = ids.shape
         dy2 = dy.reshape(B * L, 768).contiguous()
-        de, dg, db = ops.layernorm_bwd(dy2, e, lnw.detach(), mean, rstd)
+        de, dg, db = ops.layernorm_bwd(dy2, e, lnw.detach(), mean, rstd, out_gamma=_grad_buf(lnw), out_beta=_grad_buf(lnb))
         gv = _grad_buf(word)
         if gv is not None:
             gv.zero_()
@@ -217,7 +217,7 @@ class TextEmbedFn(torch.autograd.Function):
             dword = ops.text_embed_bwd(ids, de, word.shape[0])
         dpos = torch.zeros_like(pos)
         dpos[:L] = ops.colsum_grouped(de, B, 768, L * 768, B, 0, L, 768)          # sum over the batch per position
-        return None, dword, _into(pos, dpos), _into(lnw, dg), _into(lnb, db), None
+        return None, dword, _into(pos, dpos), dg, db, None
 
 
 class BertLayerFn(torch.autograd.Function):
@@ -255,14 +255,14 @@ class BertLayerFn(torch.autograd.Function):
         B, L = ctx.dims
         cd = x2.dtype
         dy2 = dy.reshape(B * L, -1).contiguous()
-        ds2, dl2w, dl2b = ops.layernorm_bwd(dy2, s2, l2w.detach(), m2, r2)
+        ds2, dl2w, dl2b = ops.layernorm_bwd(dy2, s2, l2w.detach(), m2, r2, out_gamma=_grad_buf(l2w), out_beta=_grad_buf(l2b))
         df2b = _bgrad(ds2, f2b)
         df2w = _wgrad(ds2, a, f2w)
         dpre = ops.linear_bwd_input(ds2, SHADOWS.get(f2w, cd), gelu_pre=pre)
         df1b = _bgrad(dpre, f1b)
         df1w = _wgrad(dpre, x1, f1w)
         dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
-        ds1, dl1w, dl1b = ops.layernorm_bwd(dx1, s1, l1w.detach(), m1, r1)
+        ds1, dl1w, dl1b = ops.layernorm_bwd(dx1, s1, l1w.detach(), m1, r1, out_gamma=_grad_buf(l1w), out_beta=_grad_buf(l1b))
         dob = _bgrad(ds1, ob)
         dow = _wgrad(ds1, att, ow)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))
@@ -272,8 +272,7 @@ class BertLayerFn(torch.autograd.Function):
         dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
         ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
         ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)
-        return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, _into(l1w, dl1w), _into(l1b, dl1b), df1w, df1b,
-                df2w, df2b, _into(l2w, dl2w), _into(l2b, dl2b), None)
+        return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, dl1w, dl1b, df1w, df1b, df2w, df2b, dl2w, dl2b, None)
 
 
 # ----------------------------------------------------------------------------------------------------------------

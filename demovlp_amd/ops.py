@@ -128,8 +128,9 @@ def colsum(x2d, out=None, accumulate=False):
     return out
 
 
-def colsum_grouped(x, M, N, ld, inner, ostride, groups, gstride):
-    out = torch.empty((groups, N), device=x.device, dtype=torch.float32)
+def colsum_grouped(x, M, N, ld, inner, ostride, groups, gstride, out=None):
+    if out is None:
+        out = torch.empty((groups, N), device=x.device, dtype=torch.float32)
     ws = _workspace("colsum", groups * call("dvlp_colsum_chunks", M) * N, x.device)
     call("dvlp_colsum", dt(x), M, N, p(x), ld, inner, ostride, groups, gstride, p(out), p(ws), 0, stream())
     return out
@@ -148,11 +149,15 @@ def layernorm_fwd(x2d, gamma, beta, eps, want_relu=False):
     return y, yr, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None):
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_beta=None):
+    """``out_gamma`` / ``out_beta``: optional fp32 destinations (e.g. gradient-arena slices); contiguous pairs reduce in one launch."""
     M, D = x2d.shape
     dx = torch.empty_like(x2d)
-    gb = torch.empty(2 * D, device=x2d.device, dtype=torch.float32)      # contiguous pair -> one reduction launch
-    dgamma, dbeta = gb[:D], gb[D:]
+    if out_gamma is not None and out_beta is not None:
+        dgamma, dbeta = out_gamma, out_beta
+    else:
+        gb = torch.empty(2 * D, device=x2d.device, dtype=torch.float32)      # contiguous pair -> one reduction launch
+        dgamma, dbeta = gb[:D], gb[D:]
     ws = _workspace("ln", (call("dvlp_layernorm_bwd_blocks", M) + 1) * 2 * D, x2d.device)
     call("dvlp_layernorm_bwd", dt(x2d), M, D, p(dy2d), p(x2d), p(gamma), p(mean), p(rstd), p(dres), p(dx), p(dgamma), p(dbeta),
          p(ws), 0, stream())
@@ -229,9 +234,10 @@ def embed_unassemble(dx, B, F, R):
     return dtok
 
 
-def box_wgrad(dtok, box):
+def box_wgrad(dtok, box, out=None):
     M = dtok.shape[0]
-    out = torch.empty((768, 6), device=dtok.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((768, 6), device=dtok.device, dtype=torch.float32)
     ws = _workspace("boxw", call("dvlp_box_wgrad_chunks", M) * 6 * 768, dtok.device)
     call("dvlp_box_wgrad", dt(dtok), M, p(dtok), p(box), p(out), p(ws), 0, stream())
     return out

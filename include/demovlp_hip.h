@@ -43,6 +43,8 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
                       int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
 /* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
 int dvlp_gemm_variant(int use_lds_dma);
+/* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
+int dvlp_gemm_splitk_target(int64_t n);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */
 int dvlp_set_workspace(void* ptr, int64_t bytes);
 /* per-launch HIP-event timing of the GEMM kernels (bench.py roofline figure) */

@@ -28,8 +28,10 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--tokens", type=int, default=18496)
     ap.add_argument("--variant", type=int, default=1, help="1 = LDS-DMA kernel, 0 = register-staged kernel")
+    ap.add_argument("--splitk-target", type=int, default=768)
     a = ap.parse_args()
     ops.call("dvlp_gemm_variant", a.variant)
+    ops.call("dvlp_gemm_splitk_target", a.splitk_target)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
     M = a.tokens
