@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256) void reduce_groups_kernel(int64_t P, int64_t C
 // two for fp32) of every 8th row, then the 8 row-lanes are combined through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const T* __restrict__ x, int64_t ld, int64_t inner, int64_t ostride,
-                                                     int64_t gstride, int64_t rows_per, float* __restrict__ partial, int vec) {
+                                                     int64_t gstride, int64_t rows_per, float* __restrict__ partial, int vec,
+                                                     unsigned* __restrict__ counters, float* __restrict__ out, int accumulate) {
     __shared__ float red[8][256 + 8];
+    __shared__ int s_last;
     const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int64_t n = (int64_t)blockIdx.x * 256 + cc * 8;
     const int64_t g = blockIdx.z;
@@ -171,6 +173,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
         partial[(g * gridDim.y + blockIdx.y) * N + col] = s;
+    }
+    if (!counters) return;
+    // Fused second stage (saves a launch per bias gradient): the LAST row-chunk workgroup of this (group, column block)
+    // to arrive sums the partials.  Placement-independent hand-off: every storing wave drains its stores, the workgroup
+    // barrier, then one lane releases at agent scope and takes a ticket; the last arriver acquires at agent scope before
+    // any lane reads the other workgroups' partials (cdna_hip_programming.md Guideline 16, counter form).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* cnt = counters + g * gridDim.x + blockIdx.x;
+        const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == gridDim.y - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm for the next call
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last && col < N) {
+        float t = 0.f;
+        const float* src = partial + g * gridDim.y * N + col;
+        for (unsigned p = 0; p < gridDim.y; ++p) t += src[(int64_t)p * N];
+        out[g * N + col] = accumulate ? out[g * N + col] + t : t;
     }
 }
 
@@ -213,7 +242,13 @@ extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* d
 
 // out[g][n] (+)= sum_m x_g[m][n]   (bias / embedding-table gradients).  Row m of group g is at
 // x + g*gstride + (m / inner)*ostride + (m % inner)*ld  (plain [M, ld] matrix: inner = M, groups = 1).
-// workspace: fp32 [groups * dvlp_colsum_chunks(M) * N]
+// workspace: fp32 [groups * dvlp_colsum_chunks(M) * N] (+ optional counters, see dvlp_colsum_counters)
+// Zero-initialised device counters (one per (group, 256-column block)) enabling the fused single-launch reduction of
+// dvlp_colsum; caller-owned, must stay zero between calls (the kernel re-arms them).  NULL: two-launch path.
+static unsigned* g_colsum_counters = nullptr;
+static int64_t g_colsum_ncounters = 0;
+extern "C" int dvlp_colsum_counters(void* ptr, int64_t count) { g_colsum_counters = (unsigned*)ptr; g_colsum_ncounters = ptr ? count : 0; return DVLP_OK; }
+
 extern "C" int64_t dvlp_colsum_chunks(int64_t M) { const int64_t c = cdiv(M, 64); return c < 192 ? c : 192; }
 
 extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
@@ -225,9 +260,10 @@ extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64
     dim3 grid((unsigned)cdiv(N, 256), (unsigned)P, (unsigned)groups), block(256);
     const int64_t al = dtype == DVLP_F32 ? 4 : 8;      // elements per 16 bytes
     const int vec = (ld % al == 0) && (ostride % al == 0) && (gstride % al == 0) && ((uintptr_t)x % 16 == 0);
-    if (dtype == DVLP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, M, N, (const float*)x, ld, inner, ostride, gstride, rows_per, workspace, vec);
-    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)x, ld, inner, ostride, gstride, rows_per, workspace, vec);
+    unsigned* cnt = g_colsum_counters && groups * cdiv(N, 256) <= g_colsum_ncounters ? g_colsum_counters : nullptr;
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, M, N, (const float*)x, ld, inner, ostride, gstride, rows_per, workspace, vec, cnt, out, accumulate);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)x, ld, inner, ostride, gstride, rows_per, workspace, vec, cnt, out, accumulate);
     else return DVLP_ERR_DTYPE;
-    hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)groups), dim3(256), 0, st, P, N, workspace, out, accumulate);
+    if (!cnt) hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)groups), dim3(256), 0, st, P, N, workspace, out, accumulate);
     return dvlp_launch_status();
 }

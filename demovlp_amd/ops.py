@@ -118,11 +118,29 @@ def _workspace(key, nfloat, device):
     return t
 
 
+_COLSUM_CNT = {}
+
+
+FUSED_COLSUM = False      # measured on MI355X: the agent-scope release per workgroup (L2 write-back) costs more than the
+                          # second launch it saves (step 39.5 -> 43.4 ms), so the two-launch reduction stays the default
+
+
+def _ensure_colsum_counters(device):
+    if not FUSED_COLSUM:
+        return
+    key = str(device)
+    if key not in _COLSUM_CNT:
+        t = torch.zeros(4096, device=device, dtype=torch.int32)
+        _COLSUM_CNT[key] = t
+        call("dvlp_colsum_counters", p(t), t.numel())
+
+
 def colsum(x2d, out=None, accumulate=False):
     """fp32 [N] = sum over rows of x [M,N] (bias gradients)."""
     M, N = x2d.shape
     if out is None:
         out = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    _ensure_colsum_counters(x2d.device)
     ws = _workspace("colsum", call("dvlp_colsum_chunks", M) * N, x2d.device)
     call("dvlp_colsum", dt(x2d), M, N, p(x2d), x2d.stride(0), M, 0, 1, 0, p(out), p(ws), int(accumulate), stream())
     return out
@@ -131,6 +149,7 @@ def colsum(x2d, out=None, accumulate=False):
 def colsum_grouped(x, M, N, ld, inner, ostride, groups, gstride, out=None):
     if out is None:
         out = torch.empty((groups, N), device=x.device, dtype=torch.float32)
+    _ensure_colsum_counters(x.device)
     ws = _workspace("colsum", groups * call("dvlp_colsum_chunks", M) * N, x.device)
     call("dvlp_colsum", dt(x), M, N, p(x), ld, inner, ostride, groups, gstride, p(out), p(ws), 0, stream())
     return out

@@ -60,6 +60,8 @@ int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const vo
                        void* stream);
 /* bias / table gradients: out[g][n] (+)= sum_m x_g[m][n] */
 int64_t dvlp_colsum_chunks(int64_t M);
+/* optional: `count` zeroed uint32 counters enabling the single-launch (last-workgroup-reduces) form of dvlp_colsum */
+int dvlp_colsum_counters(void* ptr, int64_t count);
 int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
                 int64_t gstride, float* out, float* workspace, int accumulate, void* stream);
 

@@ -186,3 +186,15 @@ def test_data_parallel_plumbing_gloo_world2():
     for p in procs:
         p.join(60)
     assert all(g and r for _, g, r in res), res
+
+
+def test_retrieval_metrics_match_reference_golden():
+    """demovlp_amd.metric against vectors produced by the reference's model/metric.py (ties included)."""
+    from demovlp_amd import metric
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g7_metrics.npz"))
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    for tag in ("sq64", "rect"):
+        sims = g[tag + "_sims"]
+        for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
+            got = fn(sims.copy())
+            assert np.allclose([got[k] for k in keys], g[f"{tag}_{name}"], rtol=1e-12, atol=1e-12), (tag, name)
