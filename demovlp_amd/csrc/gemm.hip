@@ -454,14 +454,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 //   form R tile [64 k][128 rows]  (256-B rows): chunk c of k-row k lives in slot c ^ (2 m(k)),
 //                                 m(k) = 4 ((k >> 3) & 1) + (k & 3)                                 -> ds_read_b64_tr_b16
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int G_TILE_B = 16384;    // bytes per operand tile per stage
+// Tile geometry of the LDS-DMA kernel: BN = 128, BK = 64, WM waves along M (2 -> BM = 128, 256 threads, 2 workgroups per
+// CU; 4 -> BM = 256, 512 threads, 1 workgroup per CU).  The K loop is bound by the L2 -> LDS fill rate (measured ~10 TB/s
+// chip-wide: 128x128 tiles give 64 FLOP per filled byte = ~650 TFLOP/s), so the wide tile (96 FLOP/B) is preferred
+// whenever the grid still fills the chip.
+template <int ROWS> struct GTile { static constexpr int BYTES = ROWS * 128; };
 
-template <bool FORM_R>
+template <bool FORM_R, int ROWS, int NW>
 __device__ __forceinline__ void g_issue(char* lds_tile, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
                                         int wid, int lane) {
+    constexpr int PIECES = ROWS / 8, PER_WAVE = PIECES / NW;       // 1-KiB pieces of the tile
+    constexpr int CPR = ROWS / 8;                                    // form R: 16-byte chunks per k-row
+    constexpr int KPP = 64 / CPR;                                    // form R: k-rows per piece
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = wid * 4 + j;                      // 1-KiB piece (wave-uniform)
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int q = wid * PER_WAVE + j;                          // piece index (wave-uniform)
         const bf16* src;
         if (!FORM_R) {
             const int rl = 8 * q + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
@@ -469,7 +476,7 @@ __device__ __forceinline__ void g_issue(char* lds_tile, const bf16* __restrict__
             gr = gr > R - 1 ? R - 1 : gr;
             src = X + gr * ld + k0 + c * 8;
         } else {
-            const int kl = 4 * q + (lane >> 4), m = ((kl >> 3) & 1) * 4 + (kl & 3), c = (lane & 15) ^ (m << 1);
+            const int kl = KPP * q + lane / CPR, m = ((kl >> 3) & 1) * 4 + (kl & 3), c = (lane % CPR) ^ (m << 1);
             int64_t gr = r0 + c * 8;
             gr = gr > R - 8 ? R - 8 : gr;
             src = X + (k0 + kl) * ld + gr;
@@ -479,35 +486,39 @@ __device__ __forceinline__ void g_issue(char* lds_tile, const bf16* __restrict__
     }
 }
 
-// 8 transposing reads (4 fragments x lo/hi) from 4 per-fragment addresses; no wait (see g_wait8)
+// 8 transposing reads (4 fragments x lo/hi) from 4 per-fragment addresses; hi = +4 k-rows = +HI bytes; no wait (g_wait8)
+template <int HI>
 __device__ __forceinline__ void g_tr8(bf16x4 (&lo)[4], bf16x4 (&hi)[4], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
     asm volatile(
         "ds_read_b64_tr_b16 %0, %8\n\t"
-        "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
         "ds_read_b64_tr_b16 %2, %9\n\t"
-        "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
         "ds_read_b64_tr_b16 %4, %10\n\t"
-        "ds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
         "ds_read_b64_tr_b16 %6, %11\n\t"
-        "ds_read_b64_tr_b16 %7, %11 offset:1024"
+        "ds_read_b64_tr_b16 %7, %11 offset:%12"
         : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "i"(HI) : "memory");
 }
 // retire every outstanding LDS read; naming the destinations makes every consumer depend on this statement
 __device__ __forceinline__ void g_wait8(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]) :: "memory");
 }
 
-template <bool A_R, bool B_R>
-__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
-                                                             const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
-                                                             Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
+template <bool A_R, bool B_R, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
+                                                                  const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                                  Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
+    constexpr int NW = 2 * WM, BM = 64 * WM, BN = 128;
+    constexpr int A_B = GTile<BM>::BYTES, B_B = GTile<BN>::BYTES, STAGE = A_B + B_B;
+    constexpr int A_ROWB = BM * 2, B_ROWB = BN * 2;               // form R: bytes per k-row
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
     int64_t tm_, tn_;
     tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
-    const int64_t m0 = tm_ * H_BM, n0 = tn_ * H_BN;
+    const int64_t m0 = tm_ * BM, n0 = tn_ * BN;
     A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
     if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
     if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
@@ -526,36 +537,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(int64_t M, int64_t 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (!A_R) offA[i] = (unsigned)((wm + 16 * i + r) * 128);                                      // + slot*16 per k-step
-        else      offA[i] = (unsigned)((8 * g + qq) * 256 + ((((wm >> 3) + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
+        else      offA[i] = (unsigned)((8 * g + qq) * A_ROWB + ((((wm >> 3) + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
         if (!B_R) offB[i] = (unsigned)((wn + 16 * i + r) * 128);
-        else      offB[i] = (unsigned)((8 * g + qq) * 256 + ((((wn >> 3) + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
+        else      offB[i] = (unsigned)((8 * g + qq) * B_ROWB + ((((wn >> 3) + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
     }
     const unsigned lds0 = (unsigned)(uintptr_t)smem_raw;
 
     auto issue = [&](int64_t kt, int st) {
-        char* base = smem_raw + st * 2 * G_TILE_B;
-        g_issue<A_R>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane);
-        g_issue<B_R>(base + G_TILE_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane);
+        char* base = smem_raw + st * STAGE;
+        g_issue<A_R, BM, NW>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane);
+        g_issue<B_R, BN, NW>(base + A_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane);
     };
     issue(0, 0);
     __syncthreads();                                   // also drains the LDS-DMA (vmcnt(0))
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int cur = (int)(kt & 1);
         if (kt + 1 < nk) issue(kt + 1, cur ^ 1);       // stage cur^1 was last read before the previous barrier
-        const unsigned tA = lds0 + cur * 2 * G_TILE_B, tB = tA + G_TILE_B;
+        const unsigned tA = lds0 + cur * STAGE, tB = tA + A_B;
         bf16x8 af[2][4], bfr[2][4];
         bf16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (A_R) g_tr8(alo[s], ahi[s], tA + offA[0] + s * 8192, tA + offA[1] + s * 8192, tA + offA[2] + s * 8192, tA + offA[3] + s * 8192);
+            if (A_R) g_tr8<4 * A_ROWB>(alo[s], ahi[s], tA + offA[0] + s * 32 * A_ROWB, tA + offA[1] + s * 32 * A_ROWB, tA + offA[2] + s * 32 * A_ROWB, tA + offA[3] + s * 32 * A_ROWB);
             else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[s][i] = *(const bf16x8*)(smem_raw + cur * 2 * G_TILE_B + offA[i] + ((((4 * s + g) ^ (r & 7))) << 4));
+                for (int i = 0; i < 4; ++i) af[s][i] = *(const bf16x8*)(smem_raw + cur * STAGE + offA[i] + ((((4 * s + g) ^ (r & 7))) << 4));
             }
-            if (B_R) g_tr8(blo[s], bhi[s], tB + offB[0] + s * 8192, tB + offB[1] + s * 8192, tB + offB[2] + s * 8192, tB + offB[3] + s * 8192);
+            if (B_R) g_tr8<4 * B_ROWB>(blo[s], bhi[s], tB + offB[0] + s * 32 * B_ROWB, tB + offB[1] + s * 32 * B_ROWB, tB + offB[2] + s * 32 * B_ROWB, tB + offB[3] + s * 32 * B_ROWB);
             else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bfr[s][i] = *(const bf16x8*)(smem_raw + cur * 2 * G_TILE_B + G_TILE_B + offB[i] + ((((4 * s + g) ^ (r & 7))) << 4));
+                for (int i = 0; i < 4; ++i) bfr[s][i] = *(const bf16x8*)(smem_raw + cur * STAGE + A_B + offB[i] + ((((4 * s + g) ^ (r & 7))) << 4));
             }
         }
 #pragma unroll
@@ -579,28 +590,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(int64_t M, int64_t 
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
         __syncthreads();
     }
-    float* Ct = (float*)smem_raw + wid * (64 * 68);
+    // epilogue through LDS in two 32-row passes (8.7 KB per wave per pass, so 8 waves fit the 96 KB of the wide variant)
+    float* Ct = (float*)smem_raw + wid * (32 * 68);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int hp = 0; hp < 2; ++hp) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) Ct[(16 * i + 4 * (lane >> 4) + rr) * 68 + 16 * j + (lane & 15)] = acc[i][j][rr];
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Ct[(16 * i + 4 * (lane >> 4) + rr) * 68 + 16 * j + (lane & 15)] = acc[2 * hp + i][j][rr];
 #pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
-        const int64_t m = m0 + wm + row, n = n0 + wn + col;
-        const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
-        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        if (m < M && n < N) {
-            if (slab) {
-                float* dst = slab + ((int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M + m) * N + n;
-                if ((N & 3) == 0 && n + 7 < N) { *(float4*)dst = c0; *(float4*)(dst + 4) = c1; }
-                else {
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+            const int64_t m = m0 + wm + 32 * hp + row, n = n0 + wn + col;
+            const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
+            float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            if (m < M && n < N) {
+                if (slab) {
+                    float* dst = slab + ((int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M + m) * N + n;
+                    if ((N & 3) == 0 && n + 7 < N) { *(float4*)dst = c0; *(float4*)(dst + 4) = c1; }
+                    else {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) if (n + t < N) dst[t] = v[t];
-                }
-            } else epi_store8(e, C, ldc, m, n, v, N);
+                        for (int t = 0; t < 8; ++t) if (n + t < N) dst[t] = v[t];
+                    }
+                } else epi_store8(e, C, ldc, m, n, v, N);
+            }
         }
     }
 }
@@ -638,6 +653,8 @@ extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipE
 
 // A/B switch between the LDS-DMA kernel (default) and the register-staged one (tools/gemm_bench.py --variant)
 static bool g_use_glds = true;
+static int g_wide_mode = 1;      // 0: never use the 256-row tile, 1: heuristic, 2: always (when the LDS-DMA kernel applies)
+extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
 extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
 extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
@@ -728,11 +745,18 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
         hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
-#define LAUNCH_GLDS_(AR, BR) do { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
-                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
+#define LAUNCH_GLDS_(AR, BR) do { if (wide) { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128); } \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4>), gridw, dim3(512), (size_t)2 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } else { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 2>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } } while (0)
         const bool dma = !safe && K % H_BK == 0 && g_use_glds;
+        // wide (256 x 128) tiles when they still give every CU at least ~2 workgroups; A form R needs M % 8 (guaranteed by !safe)
+        const int64_t ntm_w = cdiv(M, 256);
+        const bool wide = dma && g_wide_mode != 0 && (g_wide_mode == 2 || ntm_w * ntn * batch * S >= 512);
+        dim3 gridw((unsigned)(ntm_w * ntn), (unsigned)batch, (unsigned)S);
 #define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         if (!transA && !transB) LAUNCH_BF16(false, false);
         else if (!transA && transB) LAUNCH_BF16(false, true);

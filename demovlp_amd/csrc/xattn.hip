@@ -29,8 +29,13 @@ static inline int64_t rup(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 struct XLayout {
     int64_t Bi, Bj, G, W, Gp, Wp, es;   // es = element size
     int64_t off_chat, off_qhat, off_S, off_P1, off_P2, off_wc, off_wc2, off_st1, off_st2, off_dP1, off_dP2, off_dchat, off_dqhat,
-        off_dirc, off_dirq, total;
+        off_dirc, off_dirq, off_rinv, off_cinv, off_rpart, off_cpart, total;
 };
+static size_t pair_lds(int64_t G, int64_t W, int bwd);
+static bool g_force_general = false;
+extern "C" int dvlp_xattn_force_general(int on) { g_force_general = on != 0; return DVLP_OK; }
+static bool x_general(int64_t G, int64_t W) { return g_force_general || pair_lds(G, W, 1) > 160 * 1024; }
+
 static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
     XLayout L{};
     L.Bi = Bi; L.Bj = Bj; L.G = G; L.W = W; L.Gp = rup(G, 8); L.Wp = rup(W, 8); L.es = dtype == DVLP_F32 ? 4 : 2;
@@ -52,6 +57,14 @@ static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, 
         L.off_dqhat = take(Bj * L.Wp * XD * L.es);
         L.off_dirc = take(Bi * G * XD * 4);
         L.off_dirq = take(Bj * W * XD * 4);
+    }
+    if (x_general(G, W)) {       // general-G path: reciprocal norms and partial dot products
+        L.off_rinv = take(Bi * Bj * G * 4);
+        L.off_cinv = take(Bi * Bj * L.Wp * 4);
+        if (bwd) {
+            L.off_rpart = take(Bi * Bj * cdiv(L.Wp, 8) * G * 4);
+            L.off_cpart = take(Bi * Bj * cdiv(G, 64) * L.Wp * 4);
+        }
     }
     L.total = o;
     return L;
@@ -344,6 +357,236 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// General-G softmax stage (long video: F*R = 1152 regions does not fit the fused kernels' LDS tile).  The pair's work is
+// split over workgroups: image->text per chunk of XWC words (needs all regions of those words: an [G][XWC] tile),
+// text->image per chunk of 64 regions (rows are independent, no LDS), norms in a pre-pass, and the cross-chunk dot
+// products <dA,S> travel through small fp32 partial buffers (no atomics).  Softmax uses the bound z <= lambda (|A| <= 1,
+// masks <= 0) instead of a max pass.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int XWC = 8;          // words per image->text workgroup
+constexpr int XWS = XWC + 1;    // padded LDS row
+
+struct GenArgs {
+    PairArgs p;
+    float *rinv, *cinv;         // [Bi][Bj][G], [Bi][Bj][Wp]   reciprocal norms
+    float *rpart, *cpart;       // [Bi][Bj][WC][G], [Bi][Bj][GC][Wp]   partial <dA,S> per word chunk / region chunk
+    int WC, GC;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void xg_norm_kernel(GenArgs a) {
+    __shared__ float csq[4][128];
+    const PairArgs& p = a.p;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = blockIdx.x, i = blockIdx.y;
+    const T* S = (const T*)p.S;
+    float c0 = 0.f, c1 = 0.f;
+    for (int g = wid; g < p.G; g += 4) {
+        const T* row = S + (((int64_t)i * p.G + g) * p.Bj + j) * p.Wp;
+        const float v0 = lane < p.W ? to_f(row[lane]) : 0.f, v1 = lane + 64 < p.W ? to_f(row[lane + 64]) : 0.f;
+        c0 += v0 * v0; c1 += v1 * v1;
+        const float q = wave_sum(v0 * v0 + v1 * v1);
+        if (lane == 0) a.rinv[((int64_t)i * p.Bj + j) * p.G + g] = 1.f / (sqrtf(q) + 1e-8f);
+    }
+    csq[wid][lane] = c0; csq[wid][lane + 64] = c1;
+    __syncthreads();
+    for (int w = threadIdx.x; w < p.W; w += blockDim.x)
+        a.cinv[((int64_t)i * p.Bj + j) * p.Wp + w] = 1.f / (sqrtf(csq[0][w] + csq[1][w] + csq[2][w] + csq[3][w]) + 1e-8f);
+}
+
+// image -> text for XWC words of one pair.  BWD = false: write P1 rows.  BWD = true: dP1 rows in, dA r^-1 rows out (in
+// place) + this chunk's partial <dA, S> per region.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void xg_i2t_kernel(GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const PairArgs& p = a.p;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wc = blockIdx.x, j = blockIdx.y, i = blockIdx.z, w0 = wc * XWC;
+    const int G = p.G;
+    float* St = sm;                     // [G][XWS] S
+    float* Et = St + G * XWS;           // [G][XWS] e -> P -> (bwd) dA
+    float* Dt = Et + G * XWS;           // [G][XWS] dP'  (bwd only)
+    const T* S = (const T*)p.S;
+    const float* rinv = a.rinv + ((int64_t)i * p.Bj + j) * G;
+    const float* mimg = p.mimg + (int64_t)i * G;
+    for (int idx = threadIdx.x; idx < G * XWC; idx += blockDim.x) {
+        const int g = idx / XWC, c = idx % XWC, w = w0 + c;
+        St[g * XWS + c] = w < p.W ? to_f(S[(((int64_t)i * G + g) * p.Bj + j) * p.Wp + w]) : 0.f;
+    }
+    T* P1 = (T*)(BWD ? p.dP1 : p.P1) + ((int64_t)i * p.Bj + j) * p.Wp * p.Gp;
+    if (BWD) {
+        for (int c = wid; c < XWC; c += 4) {
+            const int w = w0 + c;
+            for (int g = lane; g < G; g += 64) Dt[g * XWS + c] = w < p.W ? to_f(P1[(int64_t)w * p.Gp + g]) : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int c = wid; c < XWC; c += 4) {
+        const int w = w0 + c;
+        if (w >= p.Wp) continue;
+        if (w >= p.W) {                                     // pad rows of P1 stay zero
+            if (!BWD) for (int g = lane; g < p.Gp; g += 64) P1[(int64_t)w * p.Gp + g] = from_f<T>(0.f);
+            continue;
+        }
+        float sum = 0.f;
+        for (int g = lane; g < G; g += 64) {
+            const float e = __expf(p.lam * (St[g * XWS + c] * rinv[g] + mimg[g]) - p.lam);
+            Et[g * XWS + c] = e; sum += e;
+        }
+        const float inv = 1.f / wave_sum(sum);
+        float psum = 0.f;
+        for (int g = lane; g < G; g += 64) { const float P = Et[g * XWS + c] * inv; Et[g * XWS + c] = P; psum += P; }
+        psum = wave_sum(psum);
+        float sg = 0.f;
+        for (int g = lane; g < G; g += 64) {
+            const float P = Et[g * XWS + c];
+            sg += (!p.gate || (P * (float)G - psum) > 0.f) ? P : 0.f;
+        }
+        const float is = 1.f / wave_sum(sg);
+        if (!BWD) {
+            for (int g = lane; g < p.Gp; g += 64) {
+                float v = 0.f;
+                if (g < G) { const float P = Et[g * XWS + c]; v = (!p.gate || (P * (float)G - psum) > 0.f) ? P * is : 0.f; }
+                P1[(int64_t)w * p.Gp + g] = from_f<T>(v);
+            }
+        } else {
+            float d1 = 0.f;
+            for (int g = lane; g < G; g += 64) {
+                const float P = Et[g * XWS + c];
+                const float pp = (!p.gate || (P * (float)G - psum) > 0.f) ? P * is : 0.f;
+                d1 += Dt[g * XWS + c] * pp;
+            }
+            d1 = wave_sum(d1);
+            float d2 = 0.f;
+            for (int g = lane; g < G; g += 64) {
+                const float P = Et[g * XWS + c];
+                const bool on = !p.gate || (P * (float)G - psum) > 0.f;
+                const float dP = on ? (Dt[g * XWS + c] - d1) * is : 0.f;
+                Dt[g * XWS + c] = dP; d2 += dP * P;
+            }
+            d2 = wave_sum(d2);
+            for (int g = lane; g < G; g += 64) {
+                const float dA = p.lam * Et[g * XWS + c] * (Dt[g * XWS + c] - d2);
+                Et[g * XWS + c] = dA;
+                P1[(int64_t)w * p.Gp + g] = from_f<T>(dA * rinv[g]);
+            }
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+        float* rp = a.rpart + (((int64_t)i * p.Bj + j) * a.WC + wc) * G;
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < XWC; ++c) if (w0 + c < p.W) t += Et[g * XWS + c] * St[g * XWS + c];
+            rp[g] = t;
+        }
+    }
+}
+
+// text -> image for 64 regions of one pair (one region per 32-lane half, rows straight from global memory)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void xg_t2i_kernel(GenArgs a) {
+    __shared__ float cred[8][128];
+    const PairArgs& p = a.p;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    const int gc = blockIdx.x, j = blockIdx.y, i = blockIdx.z;
+    const T* S = (const T*)p.S;
+    const float* cinv = a.cinv + ((int64_t)i * p.Bj + j) * p.Wp;
+    const float* mcap = p.mcap + (int64_t)j * p.W;
+    T* P2 = (T*)(BWD ? p.dP2 : p.P2) + ((int64_t)j * p.Bi + i) * p.G * p.Wp;
+    float mc[4], ci[4], cd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int w = hl + 32 * k; mc[k] = w < p.W ? mcap[w] : 0.f; ci[k] = w < p.W ? cinv[w] : 0.f; cd[k] = 0.f; }
+    for (int r = 2 * wid + half; r < 64; r += 8) {
+        const int g = gc * 64 + r;
+        const bool ok = g < p.G;
+        const int gcl = ok ? g : p.G - 1;
+        const T* row = S + (((int64_t)i * p.G + gcl) * p.Bj + j) * p.Wp;
+        float sv[4], e[4], pp[4], s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int w = hl + 32 * k; sv[k] = w < p.W ? to_f(row[w]) : 0.f; e[k] = p.lam * (sv[k] * ci[k] + mc[k]); }
+        focal_softmax<4, false>(e, pp, p.W, hl, p.gate, s);
+        if (!BWD) {
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int w = hl + 32 * k; if (w < p.Wp) P2[(int64_t)g * p.Wp + w] = from_f<T>(w < p.W ? pp[k] : 0.f); }
+            }
+        } else {
+            float dpp[4], d1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int w = hl + 32 * k; dpp[k] = w < p.W ? to_f(P2[(int64_t)gcl * p.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
+            d1 = half_sum(d1);
+            const float is = 1.f / s;
+            float d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) * is : 0.f; d2 += dpp[k] * e[k]; }
+            d2 = half_sum(d2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int w = hl + 32 * k;
+                const float dA = ok ? p.lam * e[k] * (dpp[k] - d2) : 0.f;
+                if (ok && w < p.W) P2[(int64_t)g * p.Wp + w] = from_f<T>(dA * ci[k]);
+                cd[k] += dA * sv[k];
+            }
+        }
+    }
+    if (BWD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cred[2 * wid + half][hl + 32 * k] = cd[k];
+        __syncthreads();
+        float* cp = a.cpart + (((int64_t)i * p.Bj + j) * a.GC + gc) * p.Wp;
+        for (int w = threadIdx.x; w < p.Wp; w += blockDim.x) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += cred[k][w];
+            cp[w] = t;
+        }
+    }
+}
+
+// dS_raw for 64 regions of one pair: combine the partial dots, transpose the D1 block through LDS, apply LeakyReLU'
+template <typename T>
+__global__ __launch_bounds__(256) void xg_final_kernel(GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const PairArgs& p = a.p;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int gc = blockIdx.x, j = blockIdx.y, i = blockIdx.z, g0 = gc * 64;
+    const int ng = p.G - g0 < 64 ? p.G - g0 : 64;
+    float* tile = sm; float* rdot = tile + 64 * p.Wq; float* cdot = rdot + 64;
+    const int64_t pair = (int64_t)i * p.Bj + j;
+    const T* D1 = (const T*)p.dP1 + pair * p.Wp * p.Gp;
+    const T* D2 = (const T*)p.dP2 + ((int64_t)j * p.Bi + i) * p.G * p.Wp;
+    if (threadIdx.x < ng) {
+        float t = 0.f;
+        for (int c = 0; c < a.WC; ++c) t += a.rpart[(pair * a.WC + c) * p.G + g0 + threadIdx.x];
+        rdot[threadIdx.x] = t;
+    }
+    for (int w = threadIdx.x; w < p.W; w += blockDim.x) {
+        float t = 0.f;
+        for (int c = 0; c < a.GC; ++c) t += a.cpart[(pair * a.GC + c) * p.Wp + w];
+        cdot[w] = t;
+    }
+    for (int w = wid; w < p.W; w += 4)
+        if (lane < ng) tile[lane * p.Wq + w] = to_f(D1[(int64_t)w * p.Gp + g0 + lane]);
+    __syncthreads();
+    T* S = (T*)p.S;
+    const float* rinv = a.rinv + pair * p.G;
+    const float* cinv = a.cinv + pair * p.Wp;
+    for (int gl = wid; gl < ng; gl += 4) {
+        const int g = g0 + gl;
+        const float r = rinv[g], cr = rdot[gl] * r * r / fmaxf(1.f / r - 1e-8f, 1e-30f);
+        T* row = S + (((int64_t)i * p.G + g) * p.Bj + j) * p.Wp;
+        for (int w = lane; w < p.W; w += 64) {
+            const float c = cinv[w], cc = cdot[w] * c * c / fmaxf(1.f / c - 1e-8f, 1e-30f);
+            const float sv = to_f(row[w]);
+            const float ds = tile[gl * p.Wq + w] + to_f(D2[(int64_t)g * p.Wp + w]) - sv * (cr + cc);
+            row[w] = from_f<T>(sv > 0.f ? ds : 0.1f * ds);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // cosine stage
 // ------------------------------------------------------------------------------------------------------------------
 struct CosArgs {
@@ -510,9 +753,10 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
                               const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd,
                               void* stream) {
     dvlp_clear_status();
-    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
-    if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;      // long-video (G > ~380) tiling: not in round 1
+    const bool general = x_general(G, W);
+    if (general && (W > 128 || (size_t)G * XWS * 3 * sizeof(float) > 150 * 1024)) return DVLP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const XLayout L = xlayout(dtype, Bi, Bj, G, W, bwd);
     char* ws = (char*)workspace;
@@ -536,11 +780,24 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
     pa.lam = lam; pa.gate = gate;
-    {
+    if (!general) {
+        if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 0);
         const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 32);
         if (dtype == DVLP_F32) launch_pair<float>(false, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
         else launch_pair<bf16>(false, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
+    } else {
+        GenArgs ga{};
+        ga.p = pa; ga.rinv = (float*)(ws + L.off_rinv); ga.cinv = (float*)(ws + L.off_cinv);
+        ga.WC = (int)cdiv(Wp, XWC); ga.GC = (int)cdiv(G, 64);
+        const size_t lds = (size_t)G * XWS * 2 * sizeof(float);
+        DT(xg_norm_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, 0, st, ga);
+        if (dtype == DVLP_F32) { (void)hipFuncSetAttribute((const void*)xg_i2t_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((xg_i2t_kernel<float, false>), dim3((unsigned)ga.WC, (unsigned)Bj, (unsigned)Bi), b256, lds, st, ga);
+            hipLaunchKernelGGL((xg_t2i_kernel<float, false>), dim3((unsigned)ga.GC, (unsigned)Bj, (unsigned)Bi), b256, 0, st, ga); }
+        else { (void)hipFuncSetAttribute((const void*)xg_i2t_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((xg_i2t_kernel<bf16, false>), dim3((unsigned)ga.WC, (unsigned)Bj, (unsigned)Bi), b256, lds, st, ga);
+            hipLaunchKernelGGL((xg_t2i_kernel<bf16, false>), dim3((unsigned)ga.GC, (unsigned)Bj, (unsigned)Bi), b256, 0, st, ga); }
     }
     // wc[i] [(Bj*Wp) x d] = P1[i] [(Bj*Wp) x G] . Chat_i [G x d]
     XG(dtype, 0, 1, Bj * Wp, XD, G, P1, Gp, chat, XD, wc, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, G * XD,
@@ -560,9 +817,10 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
                               const float* mimg, const float* mcap, float lam, int gate, const float* dscores, void* workspace,
                               void* dC, void* dQ, void* stream) {
     dvlp_clear_status();
-    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || G > 64 * XMAX_NKG || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
+    if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
-    if (pair_lds(G, W, 1) > 160 * 1024) return DVLP_ERR_UNSUPPORTED;
+    const bool general = x_general(G, W);
+    if (general && (W > 128 || (size_t)G * XWS * 3 * sizeof(float) > 150 * 1024)) return DVLP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const XLayout L = xlayout(dtype, Bi, Bj, G, W, 1);
     char* ws = (char*)workspace;
@@ -587,11 +845,27 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.dP1 = dP1; pa.dP2 = dP2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
     pa.lam = lam; pa.gate = gate;
-    {
+    if (!general) {
+        if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 1);
         const int nkg = (int)cdiv(Gp, 64), nkw = (int)cdiv(Wp, 32);
         if (dtype == DVLP_F32) launch_pair<float>(true, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);      // S <- dS_raw
         else launch_pair<bf16>(true, nkg, nkw, dim3((unsigned)Bj, (unsigned)Bi), lds, st, pa);
+    } else {
+        GenArgs ga{};
+        ga.p = pa; ga.rinv = (float*)(ws + L.off_rinv); ga.cinv = (float*)(ws + L.off_cinv);
+        ga.rpart = (float*)(ws + L.off_rpart); ga.cpart = (float*)(ws + L.off_cpart);
+        ga.WC = (int)cdiv(Wp, XWC); ga.GC = (int)cdiv(G, 64);
+        const size_t lds = (size_t)G * XWS * 3 * sizeof(float), lds3 = (size_t)(64 * (W | 1) + 64 + W) * sizeof(float);
+        dim3 gA((unsigned)ga.WC, (unsigned)Bj, (unsigned)Bi), gB((unsigned)ga.GC, (unsigned)Bj, (unsigned)Bi);
+        if (dtype == DVLP_F32) { (void)hipFuncSetAttribute((const void*)xg_i2t_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((xg_i2t_kernel<float, true>), gA, b256, lds, st, ga);
+            hipLaunchKernelGGL((xg_t2i_kernel<float, true>), gB, b256, 0, st, ga);
+            hipLaunchKernelGGL(xg_final_kernel<float>, gB, b256, lds3, st, ga); }
+        else { (void)hipFuncSetAttribute((const void*)xg_i2t_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((xg_i2t_kernel<bf16, true>), gA, b256, lds, st, ga);
+            hipLaunchKernelGGL((xg_t2i_kernel<bf16, true>), gB, b256, 0, st, ga);
+            hipLaunchKernelGGL(xg_final_kernel<bf16>, gB, b256, lds3, st, ga); }
     }
     // dChat_i [G x d] = P1[i]^T [G x Bj*Wp] . dwc[i] [Bj*Wp x d]  +  dSraw[i] [G x Bj*Wp] . Qhat [Bj*Wp x d]
     XG(dtype, 1, 1, G, XD, Bj * Wp, P1, Gp, wc, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, Bj * Wp * XD,

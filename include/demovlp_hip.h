@@ -43,6 +43,8 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
                       int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
 /* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
 int dvlp_gemm_variant(int use_lds_dma);
+/* 256 x 128 tile of the LDS-DMA kernel: 0 never, 1 heuristic (default), 2 always -- for A/B measurements */
+int dvlp_gemm_wide_mode(int mode);
 /* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
 int dvlp_gemm_splitk_target(int64_t n);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */
@@ -89,6 +91,8 @@ int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, const void* de
 int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream);
 
 /* ---- local loss: xattn_score_fast / func_attention_fast / focal_equal / cosine_similarity (model/loss.py:209-330) ---- */
+/* testing knob: 1 = always take the general-G (long-video) softmax path, even when the fused per-pair kernels fit LDS */
+int dvlp_xattn_force_general(int on);
 int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd);
 int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                    const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd, void* stream);

@@ -202,8 +202,20 @@ def test_text_embed(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Bi,Bj,G,W,gate", [(2, 2, 288, 99, True), (3, 4, 240, 99, True), (2, 3, 30, 99, True), (3, 3, 64, 17, False)])
-def test_xattn(dtype, Bi, Bj, G, W, gate):
+@pytest.mark.parametrize("Bi,Bj,G,W,gate,general", [(2, 2, 288, 99, True, False), (3, 4, 240, 99, True, False), (2, 3, 30, 99, True, False),
+                                                      (3, 3, 64, 17, False, False), (2, 2, 1152, 99, True, False),
+                                                      (2, 3, 288, 99, True, True), (3, 2, 30, 99, False, True)])
+def test_xattn(dtype, Bi, Bj, G, W, gate, general):
+    """general=True forces the long-video (general-G) softmax path on shapes the fused kernels also handle; G=1152 takes it
+    by itself (the [G, W] tile no longer fits LDS)."""
+    ops.call("dvlp_xattn_force_general", int(general))
+    try:
+        _xattn_case(dtype, Bi, Bj, G, W, gate)
+    finally:
+        ops.call("dvlp_xattn_force_general", 0)
+
+
+def _xattn_case(dtype, Bi, Bj, G, W, gate):
     rng = np.random.default_rng(7 + G)
     im = rng.standard_normal((Bi, G, 256), dtype=np.float32)
     cap = rng.standard_normal((Bj, W, 256), dtype=np.float32)

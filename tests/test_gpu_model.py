@@ -123,10 +123,15 @@ def test_fused_adamw_loss_curve_matches_oracle():
         assert abs(l_gpu.item() - l_ref.item()) < 1e-3 * max(1.0, abs(l_ref.item())), (step, l_gpu.item(), l_ref.item())
 
 
-def test_32_frame_forward_vs_golden():
+def test_32_frame_forward_and_loss_vs_golden():
+    """BASELINE config 5 shape (F=32, R=36 -> 1152 regions): encoder AND the local loss (general-G softmax path)."""
     g = load_golden("g2_model_F32_R36_B2.npz")
     model = build(32, 36)
-    with torch.no_grad():
-        out = model(batch(32, 36, 2))
+    out, gsim, xs, loss, gl, ll = run(model, batch(32, 36, 2))
     for k in ("global_object_embeddings", "local_object_embeddings", "global_text_embeddings"):
-        assert rel_err(out[k].float().cpu().numpy(), g[k]) < 1e-4, k
+        assert rel_err(out[k].detach().float().cpu().numpy(), g[k]) < 1e-4, k
+    assert rel_err(xs.detach().cpu().numpy(), g["xattn_scores"]) < 1e-4
+    got = np.array([loss.item(), gl.item(), ll.item()])
+    assert np.abs(got - g["losses"]).max() < 1e-4 * max(1.0, g["losses"][0]), (got, g["losses"])
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
