@@ -506,7 +506,7 @@ __device__ __forceinline__ void g_wait8(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]) :: "memory");
 }
 
-template <bool A_R, bool B_R, int WM>
+template <bool A_R, bool B_R, int WM, int STAGES>
 __global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
                                                                   const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
                                                                   Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
@@ -548,14 +548,32 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int
         g_issue<A_R, BM, NW>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane);
         g_issue<B_R, BN, NW>(base + A_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane);
     };
+    const int ab = e.flags >> 24;                      // timing ablations (0 in production)
+    // DMA instructions one wave issues per K tile (vmcnt bookkeeping of the 3-stage pipeline)
+    constexpr int NPW = (BM / 8) / NW + (BN / 8) / NW;
     issue(0, 0);
-    __syncthreads();                                   // also drains the LDS-DMA (vmcnt(0))
+    if (STAGES == 3) { if (nk > 1) issue(1, 1); }
+    else __syncthreads();                              // also drains the LDS-DMA (vmcnt(0))
     for (int64_t kt = 0; kt < nk; ++kt) {
-        const int cur = (int)(kt & 1);
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);       // stage cur^1 was last read before the previous barrier
+        int cur;
+        if (STAGES == 3) {
+            // Tiles kt and kt+1 are in flight.  Wait for THIS wave's pieces of tile kt only (vmcnt counts in issue order),
+            // then a raw barrier (no vmcnt(0) drain, unlike __syncthreads) makes every wave's pieces of tile kt visible and
+            // proves all waves finished reading tile kt-1, whose stage is refilled right after with tile kt+2.
+            cur = (int)(kt % 3);
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk && !(ab & 1)) issue(kt + 2, (int)((kt + 2) % 3));
+        } else {
+            cur = (int)(kt & 1);
+            if (kt + 1 < nk && !(ab & 1)) issue(kt + 1, cur ^ 1);       // stage cur^1 was last read before the previous barrier
+        }
         const unsigned tA = lds0 + cur * STAGE, tB = tA + A_B;
         bf16x8 af[2][4], bfr[2][4];
         bf16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+        if (!(ab & 2) || kt == 0) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (A_R) g_tr8<4 * A_ROWB>(alo[s], ahi[s], tA + offA[0] + s * 32 * A_ROWB, tA + offA[1] + s * 32 * A_ROWB, tA + offA[2] + s * 32 * A_ROWB, tA + offA[3] + s * 32 * A_ROWB);
@@ -582,14 +600,21 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int
                 for (int i = 0; i < 4; ++i) bfr[s][i] = __builtin_shufflevector(blo[s][i], bhi[s][i], 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
+        }
+        if (!(ab & 4)) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
-        __syncthreads();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(af[0][i]), "v"(af[1][i]), "v"(bfr[0][i]), "v"(bfr[1][i])); }
+        }
+        if (STAGES != 3) __syncthreads();
     }
+    if (STAGES == 3) __syncthreads();
     // epilogue through LDS in two 32-row passes (8.7 KB per wave per pass, so 8 waves fit the 96 KB of the wide variant)
     float* Ct = (float*)smem_raw + wid * (32 * 68);
 #pragma unroll
@@ -652,8 +677,10 @@ int g_dvlp_last_hip_error = 0;
 extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipError_t)g_dvlp_last_hip_error); }
 
 // A/B switch between the LDS-DMA kernel (default) and the register-staged one (tools/gemm_bench.py --variant)
+static int g_ablate = 0;         // tools/gemm_bench.py --ablate: 1 skip LDS-DMA issue, 2 skip LDS fragment reads, 4 skip MFMAs (TIMING ONLY)
+extern "C" int dvlp_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
 static bool g_use_glds = true;
-static int g_wide_mode = 1;      // 0: never use the 256-row tile, 1: heuristic, 2: always (when the LDS-DMA kernel applies)
+static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: measured no faster on this path's shapes), 1: heuristic, 2: always
 extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
 extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
@@ -695,7 +722,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return DVLP_ERR_SHAPE;
     if ((flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD)) && !aux) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    Epi e{bias, res, aux, ldres, ldaux, flags, alpha, strideA, strideB, strideC, strideRes, strideAux, 0};
+    Epi e{bias, res, aux, ldres, ldaux, flags | (g_ablate << 24), alpha, strideA, strideB, strideC, strideRes, strideAux, 0};
     {
         const int64_t cal = (flags & EPI_OUT_F32) ? 4 : 8;      // elements per 16 bytes of C
         bool v = (ldc % cal == 0) && ((uintptr_t)C % 16 == 0) && (strideC % cal == 0);
@@ -746,11 +773,11 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
 #define LAUNCH_GLDS_(AR, BR) do { if (wide) { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128); } \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4>), gridw, dim3(512), (size_t)2 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128); } \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4, 3>), gridw, dim3(512), (size_t)3 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } else { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 2>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 2, 2>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } } while (0)
         const bool dma = !safe && K % H_BK == 0 && g_use_glds;
         // wide (256 x 128) tiles when they still give every CU at least ~2 workgroups; A form R needs M % 8 (guaranteed by !safe)

@@ -43,6 +43,8 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
                       int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
 /* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
 int dvlp_gemm_variant(int use_lds_dma);
+/* TIMING-ONLY ablation of the LDS-DMA kernel's K loop (1 no DMA, 2 no fragment reads, 4 no MFMA); 0 in production */
+int dvlp_gemm_ablate(int bits);
 /* 256 x 128 tile of the LDS-DMA kernel: 0 never, 1 heuristic (default), 2 always -- for A/B measurements */
 int dvlp_gemm_wide_mode(int mode);
 /* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */

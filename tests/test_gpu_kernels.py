@@ -34,9 +34,17 @@ DTYPES = [torch.float32, torch.bfloat16]
 
 
 # ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[0, 2], ids=["tile128", "tile256x3stage"])
+def wide_mode(request):
+    """Run the bf16 GEMM tests on both LDS-DMA tile variants (128x128 two-stage, 256x128 three-stage counted-vmcnt)."""
+    ops.call("dvlp_gemm_wide_mode", request.param)
+    yield request.param
+    ops.call("dvlp_gemm_wide_mode", 0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(578, 768, 768), (300, 200, 104), (128, 128, 64), (1, 256, 768), (130, 2304, 768)])
-def test_gemm_forward_forms(dtype, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(578, 768, 768), (300, 200, 104), (128, 128, 64), (1, 256, 768), (130, 2304, 768), (1000, 384, 1280)])
+def test_gemm_forward_forms(dtype, M, N, K, wide_mode):
     a, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1)
     ref = a.float() @ w.float().t()
     y = ops.gemm(a, w, M, N, K)
@@ -57,7 +65,7 @@ def test_gemm_forward_forms(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_epilogues(dtype):
+def test_gemm_epilogues(dtype, wide_mode):
     M, N, K = 260, 384, 256
     a, w = rnd(M, K, dtype=dtype, scale=0.5), rnd(N, K, dtype=dtype, seed=1, scale=0.2)
     bias = rnd(N, seed=3)

@@ -29,10 +29,12 @@ def main():
     ap.add_argument("--tokens", type=int, default=18496)
     ap.add_argument("--variant", type=int, default=1, help="1 = LDS-DMA kernel, 0 = register-staged kernel")
     ap.add_argument("--splitk-target", type=int, default=768)
+    ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY: 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA")
     ap.add_argument("--wide", type=int, default=1, help="0 never / 1 heuristic / 2 always use the 256x128 tile")
     a = ap.parse_args()
     ops.call("dvlp_gemm_variant", a.variant)
     ops.call("dvlp_gemm_splitk_target", a.splitk_target)
+    ops.call("dvlp_gemm_ablate", a.ablate)
     ops.call("dvlp_gemm_wide_mode", a.wide)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
