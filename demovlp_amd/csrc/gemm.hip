@@ -687,9 +687,25 @@ extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n 
 extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
 
 // caller-provided scratch for split-K slabs (dvlp_set_workspace); nullptr disables splitting
-static float* g_ws = nullptr;
-static int64_t g_ws_bytes = 0;
-extern "C" int dvlp_set_workspace(void* ptr, int64_t bytes) { g_ws = (float*)ptr; g_ws_bytes = ptr ? bytes : 0; return DVLP_OK; }
+// One scratch buffer per stream (two GEMMs in flight on different streams must not share slabs); stream 0 entry is the
+// default for any stream without its own registration.
+#include <unordered_map>
+#include <mutex>
+struct WsEntry { float* ptr; int64_t bytes; };
+static std::unordered_map<void*, WsEntry> g_ws_map;
+static std::mutex g_ws_mu;
+extern "C" int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (ptr) g_ws_map[stream] = WsEntry{(float*)ptr, bytes}; else g_ws_map.erase(stream);
+    return DVLP_OK;
+}
+extern "C" int dvlp_set_workspace(void* ptr, int64_t bytes) { return dvlp_set_workspace_stream(nullptr, ptr, bytes); }
+static WsEntry ws_for(void* stream) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws_map.find(stream);
+    if (it == g_ws_map.end()) it = g_ws_map.find(nullptr);
+    return it == g_ws_map.end() ? WsEntry{nullptr, 0} : it->second;
+}
 
 struct ProfRec { hipEvent_t a, b; double flops; };
 static bool g_prof = false;
@@ -755,6 +771,9 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         // K so that ~3 workgroups land on every CU; partials go through fp32 slabs (deterministic, no float atomics).
         int64_t S = 1;
         const int64_t tiles = ntm * ntn * batch;
+        const WsEntry wse = ws_for(stream);
+        float* g_ws = wse.ptr;
+        const int64_t g_ws_bytes = wse.bytes;
         if (g_ws && tiles < 384 && K >= 1024) {
             S = (g_splitk_target + tiles - 1) / tiles;
             if (S > K / 256) S = K / 256;

@@ -49,12 +49,53 @@ def _grad_buf(param):
     return gv.view(gv.shape) if gv is not None else None
 
 
+OVERLAP_WGRAD = 0         # side-stream gradient work (needs gradient arenas): 0 off, 1 bias-gradient reductions only (they slip in
+                          # beside the main stream's GEMMs), 2 also the weight-gradient GEMMs (GEMM || GEMM: higher step throughput,
+                          # but each GEMM's own duration stretches, which blurs per-kernel timing)
+
+
+class _Side:
+    """Context: enqueue on the side stream everything that only feeds parameter gradients.  The tensors it reads were
+    produced on the main stream, so the side stream first waits for the main stream's current position, and the caching
+    allocator is told they are in use there."""
+
+    def __init__(self, *tensors, level=1):
+        self.tensors = tensors
+        self.on = OVERLAP_WGRAD >= level and torch.cuda.is_available()
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        main = torch.cuda.current_stream()
+        self.side = ops.side_stream()
+        self.side.wait_stream(main)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side_stream():
+    """Make the current stream wait for all side-stream gradient work (call before gradients are consumed)."""
+    if OVERLAP_WGRAD and torch.cuda.is_available():
+        torch.cuda.current_stream().wait_stream(ops.side_stream())
+
+
 def _wgrad(dy2d, x2d, param):
-    return ops.linear_bwd_weight(dy2d, x2d, out=_grad_buf(param))
+    with _Side(dy2d, x2d, level=2):
+        return ops.linear_bwd_weight(dy2d, x2d, out=_grad_buf(param))
 
 
 def _bgrad(dy2d, param):
-    return ops.colsum(dy2d, out=_grad_buf(param))
+    with _Side(dy2d):
+        return ops.colsum(dy2d, out=_grad_buf(param))
 
 
 def _into(param, value):

@@ -65,13 +65,25 @@ _GEMM_WS = {}
 
 
 def ensure_gemm_workspace(device, mbytes=160):
-    """Register (once per device) the scratch the split-K GEMM uses for its fp32 partial slabs."""
-    key = str(device)
+    """Register (once per device and stream) the scratch the split-K GEMM uses for its fp32 partial slabs."""
+    sid = torch.cuda.current_stream().cuda_stream
+    key = (str(device), sid)
     if key not in _GEMM_WS:
         t = torch.empty(mbytes * 1024 * 1024, device=device, dtype=torch.uint8)
         _GEMM_WS[key] = t
-        call("dvlp_set_workspace", p(t), t.numel())
+        call("dvlp_set_workspace_stream", ctypes.c_void_p(sid), p(t), t.numel())
     return _GEMM_WS[key]
+
+
+_SIDE = {}
+
+
+def side_stream(device=None):
+    """Secondary HIP stream for work that is off the backward critical path (weight / bias gradients)."""
+    device = torch.cuda.current_device() if device is None else device
+    if device not in _SIDE:
+        _SIDE[device] = torch.cuda.Stream(device=device)
+    return _SIDE[device]
 
 
 def linear_fwd(x2d, w, bias=None, res=None, gelu_aux=None):
@@ -110,11 +122,12 @@ _WS = {}
 
 
 def _workspace(key, nfloat, device):
-    """Reusable fp32 scratch (stream-ordered use only)."""
-    t = _WS.get((key, device))
+    """Reusable fp32 scratch, one per (purpose, device, stream): use is ordered by the stream it belongs to."""
+    k = (key, device, torch.cuda.current_stream().cuda_stream)
+    t = _WS.get(k)
     if t is None or t.numel() < nfloat:
         t = torch.empty(int(nfloat), device=device, dtype=torch.float32)
-        _WS[(key, device)] = t
+        _WS[k] = t
     return t
 
 

@@ -89,6 +89,7 @@ class FusedAdamW:
         self._need_zero = True
 
     def step(self, grad_scale=1.0):
+        Fn.join_side_stream()          # weight gradients may still be in flight on the side stream
         g = self.param_groups[0]
         a = self.arena
         # tensors without a gradient this step (norm3.*, object_model.norm.*, ...) must not be updated: zero their slices
@@ -160,7 +161,16 @@ class GradReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self._launched.add(b)
-        self._handles.append(dist.all_reduce(self.arena.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        # with weight gradients on the side stream, the collective must be ordered after BOTH streams: issue it from the
+        # side stream after making that wait for the main stream (RCCL's own stream then waits for the side stream)
+        if Fn.OVERLAP_WGRAD and self.arena.flat_g.is_cuda:
+            side = ops.side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                h = dist.all_reduce(self.arena.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(self.arena.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append(h)
 
     def begin(self):
         self._seen = set()
@@ -170,6 +180,7 @@ class GradReducer:
 
     def finish(self):
         """Call after backward: zero never-touched slices, reduce what is left, wait for everything."""
+        Fn.join_side_stream()
         a = self.arena
         for i, p in enumerate(a.params):
             if i not in self._seen:

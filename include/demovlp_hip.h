@@ -51,6 +51,8 @@ int dvlp_gemm_wide_mode(int mode);
 int dvlp_gemm_splitk_target(int64_t n);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */
 int dvlp_set_workspace(void* ptr, int64_t bytes);
+/* same, for one stream only (GEMMs running concurrently on two streams need separate slabs) */
+int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes);
 /* per-launch HIP-event timing of the GEMM kernels (bench.py roofline figure) */
 int dvlp_prof_enable(int on);
 int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);

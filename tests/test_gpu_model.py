@@ -98,8 +98,19 @@ def test_bf16_forward_backward_close_to_reference():
     assert not bad, bad[:5]
 
 
-def test_fused_adamw_loss_curve_matches_oracle():
-    """3 optimisation steps (arena + fused HF-AdamW, lr 1e-3 so the steps are visible) vs the CPU oracle: loss curve 1e-3."""
+@pytest.mark.parametrize("overlap", [0, 1, 2], ids=["one-stream", "bgrad-side-stream", "wgrad-side-stream"])
+def test_fused_adamw_loss_curve_matches_oracle(overlap):
+    """3 optimisation steps (arena + fused HF-AdamW, lr 1e-3 so the steps are visible) vs the CPU oracle: loss curve 1e-3.
+    Second variant: weight/bias-gradient kernels on the side HIP stream (the bench configuration)."""
+    import demovlp_amd.functional as Fn
+    Fn.OVERLAP_WGRAD = overlap
+    try:
+        _loss_curve_case()
+    finally:
+        Fn.OVERLAP_WGRAD = 0
+
+
+def _loss_curve_case():
     F, R, B = 8, 36, 2
     model = build(F, R)
     arena = ParamArena(model)
