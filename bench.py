@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--overlap-wgrad", type=int, default=0,
                     help="side-stream gradient work: 0 off (default: per-kernel timings stay well defined), 1 bias-gradient reductions, "
                          "2 also weight-gradient GEMMs (+6%% pairs/s, but concurrent GEMMs stretch each other)")
+    ap.add_argument("--p8", type=int, default=-1, help="override dvlp_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
     a = ap.parse_args()
 
@@ -126,6 +127,8 @@ def main():
     model.to(dev)
     import demovlp_amd.functional as Fn
     Fn.OVERLAP_WGRAD = int(a.overlap_wgrad)
+    if a.p8 >= 0:
+        ops.call("dvlp_gemm_p8_mode", a.p8)
     arena = ParamArena(model, bf16_shadow=(a.dtype == "bf16"))
     opt = FusedAdamW(arena, lr=1e-5)
     reducer = GradReducer(arena, bucket_mb=64.0) if world > 1 else None

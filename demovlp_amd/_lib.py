@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdemovlp_hip.so")
+# DEMOVLP_HIP_LIB: developer override for A/B timing of two builds of the library in one GPU session
+LIB_PATH = os.environ.get("DEMOVLP_HIP_LIB") or os.path.join(_HERE, "lib", "libdemovlp_hip.so")
 
 F32, BF16 = 0, 1
 EPI_GELU, EPI_GELU_BWD, EPI_RELU_BWD, EPI_ACCUM, EPI_LEAKY = 1, 2, 4, 8, 16

@@ -84,6 +84,32 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
+// bf16 epilogues: GELU through the Abramowitz-Stegun 7.1.26 rational form of erf (|error| <= 1.5e-7 absolute, two orders
+// below bf16 resolution): ONE v_exp_f32 shared by the erf tail and the Gaussian of the derivative, one v_rcp_f32, ~10 FMAs.
+// The libm erff/expf pair these replace cost ~100 VALU instructions per element and made the fc1 backward GEMM (57 M
+// outputs per layer) spend as long in its epilogue as in its MFMAs.  The fp32 kernels keep erff/expf (1e-4 parity path).
+__device__ __forceinline__ void gelu_fast_parts(float x, float& Phi, float& E) {
+    const float ax = fabsf(x);
+    E = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);                 // exp(-x^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189867f, ax, 1.0f));      // 1 / (1 + p |x| / sqrt(2)), p = 0.3275911
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float q = 0.5f * poly * t * E;                                          // upper tail 1 - Phi(|x|)
+    Phi = x >= 0.f ? 1.0f - q : q;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float Phi, E;
+    gelu_fast_parts(x, Phi, E);
+    return x * Phi;
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+    float Phi, E;
+    gelu_fast_parts(x, Phi, E);
+    return fmaf(x * 0.39894228040143267794f, E, Phi);
+}
+
 // hipGetLastError() is sticky per thread and also reports errors left behind by OTHER libraries' benign failed calls
 // (e.g. a failed attribute query inside the framework), so judge a launch by the error state it changes: clear before
 // launching (dvlp_clear_status) and read after (dvlp_launch_status).

@@ -37,10 +37,13 @@ __device__ __attribute__((noinline)) void epi_store(const Epi& e, T* __restrict_
     if (e.bias) v += e.bias[n];
     if (e.flags & EPI_GELU) {
         ((T*)e.aux)[m * e.ldaux + n] = from_f<T>(v);
-        v = gelu_erf(v);
+        v = sizeof(T) == 2 ? gelu_fast(v) : gelu_erf(v);
     }
     if (e.flags & EPI_LEAKY) v = v > 0.f ? v : 0.1f * v;
-    if (e.flags & EPI_GELU_BWD) v *= gelu_erf_grad(to_f(((const T*)e.aux)[m * e.ldaux + n]));
+    if (e.flags & EPI_GELU_BWD) {
+        const float h = to_f(((const T*)e.aux)[m * e.ldaux + n]);
+        v *= sizeof(T) == 2 ? gelu_fast_grad(h) : gelu_erf_grad(h);
+    }
     if (e.flags & EPI_RELU_BWD) v = to_f(((const T*)e.aux)[m * e.ldaux + n]) > 0.f ? v : 0.f;
     if (e.res) v += to_f(((const T*)e.res)[m * e.ldres + n]);
     if (e.flags & EPI_OUT_F32) {
@@ -57,8 +60,9 @@ __device__ __attribute__((noinline)) void epi_store(const Epi& e, T* __restrict_
 // one 16-byte (bf16) or two 16-byte (fp32-out) stores per lane instead of eight scattered 2-byte ones.
 __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float (&v)[8], int64_t N) {
     if (!e.vec || n + 7 >= N) {
+        const Epi ec = e;       // the out-of-line callee takes an address: hand it a copy so the caller's Epi stays in SGPRs
 #pragma unroll
-        for (int t = 0; t < 8; ++t) if (n + t < N) epi_store<bf16>(e, C, ldc, m, n + t, v[t]);
+        for (int t = 0; t < 8; ++t) if (n + t < N) epi_store<bf16>(ec, C, ldc, m, n + t, v[t]);
         return;
     }
 #pragma unroll
@@ -70,7 +74,7 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
     if (e.flags & EPI_GELU) {
         bf16x8 pre;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_erf(v[t]); }
+        for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_fast(v[t]); }
         *(bf16x8*)((bf16*)e.aux + m * e.ldaux + n) = pre;
     }
     if (e.flags & EPI_LEAKY) {
@@ -82,11 +86,62 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const float h = (float)a[t];
-            v[t] = (e.flags & EPI_GELU_BWD) ? v[t] * gelu_erf_grad(h) : (h > 0.f ? v[t] : 0.f);
+            v[t] = (e.flags & EPI_GELU_BWD) ? v[t] * gelu_fast_grad(h) : (h > 0.f ? v[t] : 0.f);
         }
     }
     if (e.res) {
         const bf16x8 r = *(const bf16x8*)((const bf16*)e.res + m * e.ldres + n);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += (float)r[t];
+    }
+    if (e.flags & EPI_OUT_F32) {
+        float* Cf = (float*)C + m * ldc + n;
+        if (e.flags & EPI_ACCUM) {
+            const float4 c0 = *(const float4*)Cf, c1 = *(const float4*)(Cf + 4);
+            v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+        }
+        *(float4*)Cf = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(Cf + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        return;
+    }
+    bf16* Cp = C + m * ldc + n;
+    if (e.flags & EPI_ACCUM) {
+        const bf16x8 c = *(const bf16x8*)Cp;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += (float)c[t];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
+    *(bf16x8*)Cp = o;
+}
+
+// epi_store8 for a whole, aligned 8-column group with the operands it would load (bias, residual, aux-in) already in
+// registers: the 256-row kernel runs one workgroup per CU, so nothing hides a dependent load inside its store loop.
+__device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float (&v)[8],
+                                               const float4 b0, const float4 b1, const bf16x8 r, const bf16x8 a) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] *= e.alpha;
+    if (e.bias) { v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
+    if (e.flags & EPI_GELU) {
+        bf16x8 pre;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_fast(v[t]); }
+        *(bf16x8*)((bf16*)e.aux + m * e.ldaux + n) = pre;
+    }
+    if (e.flags & EPI_LEAKY) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = v[t] > 0.f ? v[t] : 0.1f * v[t];
+    }
+    if (e.flags & EPI_GELU_BWD) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] *= gelu_fast_grad((float)a[t]);
+    }
+    if (e.flags & EPI_RELU_BWD) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = (float)a[t] > 0.f ? v[t] : 0.f;
+    }
+    if (e.res) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] += (float)r[t];
     }
@@ -645,6 +700,314 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4), one workgroup per CU, ping-pong schedule ("p8": 8 phases per two K tiles).
+//
+// Why: the 128 x 128 kernel above reads 16 KiB of LDS per wave per K tile for 32 MFMAs -- on a CU that is exactly the LDS
+// bandwidth (128 B/clk) the MFMA pipes need at full rate, so with fills and barriers on top it settles near a third of
+// peak.  Here a wave owns 128 x 64 outputs (24 KiB of LDS reads for 64 MFMAs: 75 % of the LDS budget at full MFMA rate),
+// and the two waves that share a SIMD run half a phase apart: while one issues its 16-MFMA cluster the other issues the
+// LDS reads of its next cluster and its share of the LDS-DMA prefetch.
+//
+// Units: a K tile is staged as four 16-KiB half tiles ("units", 128 rows x 64 k, each laid out exactly like a tile of the
+// 128-row kernel so the same swizzles and fragment-read formulas apply), in the order they are consumed:
+//        kind 0 = A rows 0..127 (A_lo)   1 = B rows 0..127 (B_lo)   2 = B rows 128..255 (B_hi)   3 = A rows 128..255 (A_hi)
+// Wave (wr, wc) owns output rows {64 wr + [0,64)} u {128 + 64 wr + [0,64)} and columns {32 wc + [0,32)} u {128 + 32 wc + [0,32)}.
+// Phase q of a K tile (16 MFMAs = one 64 x 32 quadrant x K 64):
+//        q0: read A_lo, B_lo -> acc[0..3][0..1]     q1: read B_hi -> acc[0..3][2..3]
+//        q2: read A_hi       -> acc[4..7][2..3]     q3: (no reads) -> acc[4..7][0..1]
+// Global phase P = 4 t + q stages unit u = P + 6 (one unit = 2 LDS-DMA instructions per wave), i.e. 4-5 phases ahead of
+// its first read, into the LDS slot whose last read was >= 2 phases ago (kinds 0/1 are last read in q0, 2 in q1, 3 in q2).
+//
+// Synchronisation (two raw s_barriers per phase, no vmcnt(0) in the steady state):
+//   * group wr = 1 runs one barrier behind group wr = 0, so its load segment coincides with the other group's MFMAs;
+//   * RAW: every wave waits (counted vmcnt) in phase P for all units <= P + 2, i.e. for what phase P + 1 reads; both groups
+//     have passed that wait before the barrier that opens the first read of phase P + 1;
+//   * WAR: the reads of phase p are retired by the lgkmcnt(0) that precedes its MFMAs; the slot is refilled in phase p + 2
+//     at the earliest, two barriers later for either group.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int P_UNIT = 128 * 128;        // bytes of one unit
+constexpr int P_BUF = 4 * P_UNIT;        // one K tile
+constexpr int P_LDS = 2 * P_BUF;         // 128 KiB
+
+template <int HI>
+__device__ __forceinline__ void g_tr4(bf16x4 (&lo)[2], bf16x4 (&hi)[2], unsigned a0, unsigned a1) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n\t"
+        "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+        "ds_read_b64_tr_b16 %2, %5\n\t"
+        "ds_read_b64_tr_b16 %3, %5 offset:%6"
+        : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1])
+        : "v"(a0), "v"(a1), "i"(HI) : "memory");
+}
+__device__ __forceinline__ void g_wait4(bf16x4 (&lo)[2], bf16x4 (&hi)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]) :: "memory");
+}
+template <int N> __device__ __forceinline__ void p_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// allow `units` (<= 4) staged units = 2 * units LDS-DMA instructions of this wave to stay in flight
+__device__ __forceinline__ void p_wait_units(int units) {
+    if (units >= 4) p_vmcnt<8>();
+    else if (units == 3) p_vmcnt<6>();
+    else if (units == 2) p_vmcnt<4>();
+    else if (units == 1) p_vmcnt<2>();
+    else p_vmcnt<0>();
+}
+__device__ __forceinline__ void p_glds(const bf16* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// ragged / split-K store of one 32-row pass (edge tiles, unaligned outputs, fp32 slabs): rare or cheap, so ONE out-of-line
+// copy instead of four inlined ones per kernel (the epilogue code would otherwise dwarf the K loop in the instruction cache)
+__device__ __attribute__((noinline)) void p8_store_ragged(const Epi& e, bf16* __restrict__ C, int64_t ldc, const float* Ct, int64_t mrow0, int64_t ncol,
+                                                           int64_t M, int64_t N, float* __restrict__ slab_out, int lane) {
+    const int col = (lane & 7) * 8, rsub = lane >> 3;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rsub;
+        const int64_t m = mrow0 + row;
+        const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (m < M && ncol < N) {
+            if (slab_out) {
+                float* dst = slab_out + m * N + ncol;
+                if ((N & 3) == 0 && ncol + 7 < N) { *(float4*)dst = c0; *(float4*)(dst + 4) = c1; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) if (ncol + t < N) dst[t] = v[t];
+                }
+            } else epi_store8(e, C, ldc, m, ncol, v, N);
+        }
+    }
+}
+
+template <bool A_R, bool B_R>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
+                                                           const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                           Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    int64_t tm_, tn_;
+    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
+    const int64_t m0 = tm_ * 256, n0 = tn_ * 256;
+    A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
+    if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
+    if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
+    const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    const int nk = (int)((kend - kbeg) / H_BK), U = 4 * nk;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane source pointers of this wave's two LDS-DMA pieces of every unit kind; they advance one K tile per use
+    auto src_ptr = [&](auto form_r, const bf16* X, int64_t ld, int64_t r0, int64_t R, int j) -> const bf16* {
+        const int q = wid * 2 + j;                                     // 1-KiB piece of the unit
+        if constexpr (!decltype(form_r)::value) {
+            const int rl = 8 * q + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+            int64_t gr = r0 + rl;
+            gr = gr > R - 1 ? R - 1 : gr;
+            return X + gr * ld + kbeg + c * 8;
+        } else {
+            const int kl = 4 * q + (lane >> 4), m = ((kl >> 3) & 1) * 4 + (kl & 3), c = (lane & 15) ^ (m << 1);
+            int64_t gr = r0 + c * 8;
+            gr = gr > R - 8 ? R - 8 : gr;
+            return X + (kbeg + kl) * ld + gr;
+        }
+    };
+    using FA = std::integral_constant<bool, A_R>;
+    using FB = std::integral_constant<bool, B_R>;
+    const bf16* sp[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sp[0][j] = src_ptr(FA{}, A, lda, m0, M, j);
+        sp[3][j] = src_ptr(FA{}, A, lda, m0 + 128, M, j);
+        sp[1][j] = src_ptr(FB{}, B, ldb, n0, N, j);
+        sp[2][j] = src_ptr(FB{}, B, ldb, n0 + 128, N, j);
+    }
+    const int64_t kstepA = A_R ? H_BK * lda : H_BK, kstepB = B_R ? H_BK * ldb : H_BK;
+    auto stage = [&](auto kind_, int par) {
+        constexpr int KIND = decltype(kind_)::value;
+        char* dst = smem_raw + par * P_BUF + KIND * P_UNIT + wid * 2048;
+        p_glds(sp[KIND][0], dst);
+        p_glds(sp[KIND][1], dst + 1024);
+        const int64_t ks = (KIND == 0 || KIND == 3) ? kstepA : kstepB;
+        sp[KIND][0] += ks; sp[KIND][1] += ks;
+    };
+
+    // per-lane fragment-read offsets inside a unit
+    const int g = lane >> 4, r = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    unsigned aK[2], bK[2], aR[4], bR[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        aK[s] = (unsigned)((64 * wr + r) * 128 + (((4 * s + g) ^ (r & 7)) << 4));
+        bK[s] = (unsigned)((32 * wc + r) * 128 + (((4 * s + g) ^ (r & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        aR[i] = (unsigned)((8 * g + qq) * 256 + (((8 * wr + 2 * i + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        bR[j] = (unsigned)((8 * g + qq) * 256 + (((4 * wc + 2 * j + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
+    const unsigned lds0 = (unsigned)(uintptr_t)smem_raw;
+
+    bf16x8 aF[2][4], bL[2][2], bH[2][2];                      // [k-step][fragment]
+    bf16x4 alo[2][4], ahi[2][4], bllo[2][2], blhi[2][2], bhlo[2][2], bhhi[2][2];
+    auto read_a = [&](int unit_off) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (A_R) g_tr8<1024>(alo[s], ahi[s], lds0 + unit_off + aR[0] + s * 8192, lds0 + unit_off + aR[1] + s * 8192,
+                                 lds0 + unit_off + aR[2] + s * 8192, lds0 + unit_off + aR[3] + s * 8192);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aF[s][i] = *(const bf16x8*)(smem_raw + unit_off + aK[s] + i * 2048);
+            }
+        }
+    };
+    auto read_b = [&](int unit_off, bf16x8 (&bf)[2][2], bf16x4 (&lo)[2][2], bf16x4 (&hi)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (B_R) g_tr4<1024>(lo[s], hi[s], lds0 + unit_off + bR[0] + s * 8192, lds0 + unit_off + bR[1] + s * 8192);
+            else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[s][j] = *(const bf16x8*)(smem_raw + unit_off + bK[s] + j * 2048);
+            }
+        }
+    };
+    auto land_a = [&]() {
+        if (A_R) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                g_wait8(alo[s], ahi[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aF[s][i] = __builtin_shufflevector(alo[s][i], ahi[s][i], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+    auto land_b = [&](bf16x8 (&bf)[2][2], bf16x4 (&lo)[2][2], bf16x4 (&hi)[2][2]) {
+        if (B_R) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                g_wait4(lo[s], hi[s]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[s][j] = __builtin_shufflevector(lo[s][j], hi[s][j], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+
+    auto phase = [&](auto q_, auto par_, int P) {
+        constexpr int Q = decltype(q_)::value, PAR = decltype(par_)::value;
+        // ---- load segment: fragment reads of this phase, one unit of prefetch, counted wait for what the NEXT phase reads
+        if constexpr (Q == 0) { read_b(PAR * P_BUF + 1 * P_UNIT, bL, bllo, blhi); read_a(PAR * P_BUF + 0 * P_UNIT); }
+        if constexpr (Q == 1) read_b(PAR * P_BUF + 2 * P_UNIT, bH, bhlo, bhhi);
+        if constexpr (Q == 2) read_a(PAR * P_BUF + 3 * P_UNIT);
+        if (P + 6 < U) stage(std::integral_constant<int, (Q + 2) & 3>{}, Q < 2 ? (PAR ^ 1) : PAR);
+        if constexpr (Q != 2) p_wait_units(U - 3 - P);
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMA segment
+        if constexpr (Q == 0) { land_b(bL, bllo, blhi); land_a(); }
+        if constexpr (Q == 1) land_b(bH, bhlo, bhhi);
+        if constexpr (Q == 2) land_a();
+        constexpr int MI = (Q >= 2) ? 4 : 0, NJ = (Q == 1 || Q == 2) ? 2 : 0;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[s][i], (NJ ? bH : bL)[s][j], acc[MI + i][NJ + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: units 0..5 (tile 0 and the first half of tile 1), wait for units 0 and 1
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0);
+    if (nk > 1) { stage(I0{}, 1); stage(I1{}, 1); p_vmcnt<8>(); }
+    else p_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind group 0
+    for (int t = 0; t < nk; t += 2) {
+        phase(I0{}, I0{}, 4 * t + 0); phase(I1{}, I0{}, 4 * t + 1); phase(I2{}, I0{}, 4 * t + 2); phase(I3{}, I0{}, 4 * t + 3);
+        if (t + 1 < nk) {
+            phase(I0{}, I1{}, 4 * t + 4); phase(I1{}, I1{}, 4 * t + 5); phase(I2{}, I1{}, 4 * t + 6); phase(I3{}, I1{}, 4 * t + 7);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                 // re-align the groups: every LDS read and DMA has retired
+
+    // Epilogue, per wave and without workgroup barriers: four 32-row passes (rows {lo, hi} x {first, second 32}); a pass
+    // covers the wave's 32 + 32 columns.  Accumulators go through LDS for 16-byte stores.  One workgroup per CU means no
+    // other wave hides a load inside the store loop, so the residual / aux-in rows of pass p + 1 are fetched (8 loads in
+    // flight) while pass p is stored, and parked in LDS so that the store loop stays a rolled loop.
+    constexpr int P_EPW = 32 * 68 * 4 + 2 * 4096;              // bytes per wave: staged accumulators + residual + aux-in rows
+    float* Ct = (float*)(smem_raw + wid * P_EPW);
+    bf16x8* Rs = (bf16x8*)(smem_raw + wid * P_EPW + 32 * 68 * 4);
+    bf16x8* As = Rs + 256;
+    float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
+    const int ab = e.flags >> 24;                      // timing ablations (0 in production): 8 no stores, 16 no epilogue
+    if (ab & 16) { if (acc[0][0][0] == 123.456f && acc[7][3][3] == 1.f) C[0] = (bf16)1.f; return; }
+    if (ab & 8) M = 0;
+    const int col = (lane & 7) * 8, rsub = lane >> 3;
+    const int64_t ncol = n0 + 32 * wc + (col < 32 ? col : 96 + col);
+    const bool whole = e.vec && n0 + 256 <= N && !slab_out;   // every 8-column group of this block is whole and 16-byte aligned
+    const bool has_res = e.res != nullptr, has_aux = (e.flags & (EPI_GELU_BWD | EPI_RELU_BWD)) != 0;
+    float4 bb0 = make_float4(0.f, 0.f, 0.f, 0.f), bb1 = bb0;
+    if (whole && e.bias) { bb0 = *(const float4*)(e.bias + ncol); bb1 = *(const float4*)(e.bias + ncol + 4); }
+    bf16x8 pr[4], pa[4];
+    auto mrow_of = [&](int hp) { return m0 + 128 * (hp >> 1) + 64 * wr + 32 * (hp & 1); };
+    auto preload = [&](int hp) {
+        if (!whole) return;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int64_t m = mrow_of(hp) + it * 8 + rsub;
+            m = m < M ? m : (M > 0 ? M - 1 : 0);
+            if (has_res) pr[it] = *(const bf16x8*)((const bf16*)e.res + m * e.ldres + ncol);
+            if (has_aux) pa[it] = *(const bf16x8*)((const bf16*)e.aux + m * e.ldaux + ncol);
+        }
+    };
+    preload(0);
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Ct[(16 * i + 4 * (lane >> 4) + rr) * 68 + 16 * j + (lane & 15)] = acc[2 * hp + i][j][rr];
+        const int64_t mrow0 = mrow_of(hp);
+        if (whole) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (has_res) Rs[it * 64 + lane] = pr[it];
+                if (has_aux) As[it * 64 + lane] = pa[it];
+            }
+            if (hp < 3) preload(hp + 1);
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + rsub;
+                const int64_t m = mrow0 + row;
+                const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
+                float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                bf16x8 r = {}, a = {};
+                if (has_res) r = Rs[it * 64 + lane];
+                if (has_aux) a = As[it * 64 + lane];
+                if (m < M) epi_store8_pre(e, C, ldc, m, ncol, v, bb0, bb1, r, a);
+            }
+        } else {
+            const Epi ec = e;   // see epi_store8: keep the kernel's own Epi out of scratch
+            p8_store_ragged(ec, C, ldc, Ct, mrow0, ncol, M, N, slab_out, lane);
+        }
+    }
+}
+constexpr int P_EPI_LDS = 8 * (32 * 68 * 4 + 2 * 4096);
+constexpr int P_LDS_TOTAL = P_EPI_LDS > P_LDS ? P_EPI_LDS : P_LDS;      // K-loop buffers / epilogue staging
+
 // second stage of a split-K GEMM: sum the S fp32 slabs of one output and apply the epilogue (8 columns per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int S, const float* __restrict__ slab, bf16* __restrict__ C,
                                                             int64_t ldc, Epi e) {
@@ -682,6 +1045,8 @@ extern "C" int dvlp_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
 static bool g_use_glds = true;
 static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: measured no faster on this path's shapes), 1: heuristic, 2: always
 extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
+static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
+extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
 extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
 extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
@@ -691,6 +1056,11 @@ extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 
 // default for any stream without its own registration.
 #include <unordered_map>
 #include <mutex>
+#include <map>
+#include <string>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 struct WsEntry { float* ptr; int64_t bytes; };
 static std::unordered_map<void*, WsEntry> g_ws_map;
 static std::mutex g_ws_mu;
@@ -707,7 +1077,7 @@ static WsEntry ws_for(void* stream) {
     return it == g_ws_map.end() ? WsEntry{nullptr, 0} : it->second;
 }
 
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int64_t M, N, K, batch; int form, flags, kern; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 
@@ -718,12 +1088,30 @@ extern "C" int dvlp_prof_enable(int on) {
 // Synchronises; returns the summed duration (ms), flops and count of the GEMM launches recorded since the last call.
 extern "C" int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count) {
     double ms = 0, fl = 0;
+    // DVLP_PROF_REPORT=1: per-shape table on stderr (which GEMMs of the step run below the family average)
+    struct Agg { double ms, fl; int64_t n; };
+    std::map<std::string, Agg> table;
+    const bool report = getenv("DVLP_PROF_REPORT") != nullptr;
     for (auto& r : g_recs) {
         (void)hipEventSynchronize(r.b);
         float t = 0.f;
         (void)hipEventElapsedTime(&t, r.a, r.b);
         ms += t; fl += r.flops;
+        if (report) {
+            char key[160];
+            snprintf(key, sizeof key, "%s M=%6lld N=%5lld K=%6lld b=%4lld epi=%2d kern=%s", r.form == 0 ? "KK" : r.form == 1 ? "KR" : r.form == 3 ? "RR" : "RK",
+                     (long long)r.M, (long long)r.N, (long long)r.K, (long long)r.batch, r.flags, r.kern == 2 ? "p8  " : r.kern == 1 ? "g128" : "reg ");
+            Agg& a = table[key];
+            a.ms += t; a.fl += r.flops; a.n += 1;
+        }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    if (report) {
+        std::vector<std::pair<std::string, Agg>> rows(table.begin(), table.end());
+        std::sort(rows.begin(), rows.end(), [](const auto& x, const auto& y) { return x.second.ms > y.second.ms; });
+        for (auto& kv : rows)
+            fprintf(stderr, "[gemm] %s  n=%5lld  total %9.3f ms  avg %8.1f us  %7.1f TFLOP/s\n", kv.first.c_str(), (long long)kv.second.n, kv.second.ms,
+                    1e3 * kv.second.ms / kv.second.n, kv.second.fl / (kv.second.ms * 1e-3) / 1e12);
     }
     *total_ms = ms; *total_flops = fl; *count = (int64_t)g_recs.size();
     g_recs.clear();
@@ -748,7 +1136,11 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         e.vec = v ? 1 : 0;
     }
     ProfRec rec{};
-    if (g_prof) { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); rec.flops = 2.0 * M * N * K * batch; (void)hipEventRecord(rec.a, st); }
+    if (g_prof) {
+        (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
+        rec.flops = 2.0 * M * N * K * batch; rec.M = M; rec.N = N; rec.K = K; rec.batch = batch; rec.form = transA * 2 + transB; rec.flags = flags; rec.kern = 0;
+        (void)hipEventRecord(rec.a, st);
+    }
     if (dtype == DVLP_F32) {
         const int64_t ntm = cdiv(M, F_BM), ntn = cdiv(N, F_BN);
         const int a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0) && (strideA % 4 == 0);
@@ -767,15 +1159,22 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         const int64_t ntm = cdiv(M, H_BM), ntn = cdiv(N, H_BN);
         const size_t lds = (size_t)4 * H_TILE * sizeof(bf16);
         static_assert(4 * 64 * 68 * sizeof(float) <= (size_t)4 * H_TILE * sizeof(bf16), "epilogue staging must fit the K-loop buffers");
+        // the branch-free loader clamps rows: form-K operands need >= 1 row, form-R operands a row count that is a multiple of 8
+        const bool safe = (transA ? (M % 8 != 0 || M < 8) : false) || (transB ? (N % 8 != 0 || N < 8) : false) || K < 8 || K % 8 != 0;
+        const bool dma = !safe && K % H_BK == 0 && g_use_glds;
+        // 256 x 256 ping-pong kernel: one workgroup per CU, so it wants >= ~a chip of tiles (or a K long enough to split)
+        const int64_t ntm8 = cdiv(M, 256), ntn8 = cdiv(N, 256), tiles8 = ntm8 * ntn8 * batch;
+        const bool p8 = dma && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && (tiles8 >= 192 || (tiles8 <= 64 && K >= 4096))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
-        // K so that ~3 workgroups land on every CU; partials go through fp32 slabs (deterministic, no float atomics).
+        // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32
+        // slabs (deterministic, no float atomics).
         int64_t S = 1;
-        const int64_t tiles = ntm * ntn * batch;
+        const int64_t tiles = p8 ? tiles8 : ntm * ntn * batch;
         const WsEntry wse = ws_for(stream);
         float* g_ws = wse.ptr;
         const int64_t g_ws_bytes = wse.bytes;
-        if (g_ws && tiles < 384 && K >= 1024) {
-            S = (g_splitk_target + tiles - 1) / tiles;
+        if (g_ws && tiles < (p8 ? 128 : 384) && K >= 1024) {
+            S = p8 ? 256 / tiles : (g_splitk_target + tiles - 1) / tiles;
             if (S > K / 256) S = K / 256;
             if (S > 32) S = 32;
             while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;
@@ -784,26 +1183,29 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         S = cdiv(K, kchunk);
         float* slab = S > 1 ? g_ws : nullptr;
         dim3 grid((unsigned)(ntm * ntn), (unsigned)batch, (unsigned)S), block(256);
-        // the branch-free loader clamps rows: form-K operands need >= 1 row, form-R operands a row count that is a multiple of 8
-        const bool safe = (transA ? (M % 8 != 0 || M < 8) : false) || (transB ? (N % 8 != 0 || N < 8) : false) || K < 8 || K % 8 != 0;
         // > 64 KiB of dynamic LDS must be opted into once per kernel
 #define LAUNCH_BF16_(AR, BR, SF) do { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
         hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
-#define LAUNCH_GLDS_(AR, BR) do { if (wide) { static bool once = false; if (!once) { once = true; \
+#define LAUNCH_P8_(AR, BR) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn8, kchunk, slab); } while (0)
+#define LAUNCH_GLDS_(AR, BR) do { if (p8) LAUNCH_P8_(AR, BR); else if (wide) { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128); } \
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4, 3>), gridw, dim3(512), (size_t)3 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } else { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 2, 2>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } } while (0)
-        const bool dma = !safe && K % H_BK == 0 && g_use_glds;
         // wide (256 x 128) tiles when they still give every CU at least ~2 workgroups; A form R needs M % 8 (guaranteed by !safe)
         const int64_t ntm_w = cdiv(M, 256);
-        const bool wide = dma && g_wide_mode != 0 && (g_wide_mode == 2 || ntm_w * ntn * batch * S >= 512);
+        const bool wide = dma && !p8 && g_wide_mode != 0 && (g_wide_mode == 2 || ntm_w * ntn * batch * S >= 512);
         dim3 gridw((unsigned)(ntm_w * ntn), (unsigned)batch, (unsigned)S);
+        dim3 grid8((unsigned)(ntm8 * ntn8), (unsigned)batch, (unsigned)S);
 #define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
+        rec.kern = p8 ? 2 : dma ? 1 : 0;
         if (!transA && !transB) LAUNCH_BF16(false, false);
         else if (!transA && transB) LAUNCH_BF16(false, true);
         else if (transA && transB) LAUNCH_BF16(true, true);
@@ -813,6 +1215,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
                                (const float*)slab, (bf16*)C, ldc, e);
 #undef LAUNCH_BF16_
 #undef LAUNCH_GLDS_
+#undef LAUNCH_P8_
 #undef LAUNCH_BF16
     } else {
         return DVLP_ERR_DTYPE;

@@ -47,6 +47,9 @@ int dvlp_gemm_variant(int use_lds_dma);
 int dvlp_gemm_ablate(int bits);
 /* 256 x 128 tile of the LDS-DMA kernel: 0 never, 1 heuristic (default), 2 always -- for A/B measurements */
 int dvlp_gemm_wide_mode(int mode);
+/* 256 x 256 ping-pong kernel (8 waves, counted-vmcnt LDS-DMA prefetch): 0 never, 1 where the grid suits it, 2 whenever the
+   operands allow -- for A/B measurements and tests */
+int dvlp_gemm_p8_mode(int mode);
 /* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
 int dvlp_gemm_splitk_target(int64_t n);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */

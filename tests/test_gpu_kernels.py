@@ -31,15 +31,19 @@ def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
 
 
 DTYPES = [torch.float32, torch.bfloat16]
+P8_DEFAULT = 1
 
 
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 2], ids=["tile128", "tile256x3stage"])
+@pytest.fixture(params=[(0, 0), (2, 0), (0, 2)], ids=["tile128", "tile256x3stage", "tile256sq_pingpong"])
 def wide_mode(request):
-    """Run the bf16 GEMM tests on both LDS-DMA tile variants (128x128 two-stage, 256x128 three-stage counted-vmcnt)."""
-    ops.call("dvlp_gemm_wide_mode", request.param)
+    """Run the bf16 GEMM tests on every LDS-DMA tile variant (128x128 two-stage, 256x128 three-stage counted-vmcnt,
+    256x256 ping-pong)."""
+    ops.call("dvlp_gemm_wide_mode", request.param[0])
+    ops.call("dvlp_gemm_p8_mode", request.param[1])
     yield request.param
     ops.call("dvlp_gemm_wide_mode", 0)
+    ops.call("dvlp_gemm_p8_mode", P8_DEFAULT)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -31,7 +31,9 @@ def main():
     ap.add_argument("--splitk-target", type=int, default=768)
     ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY: 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA")
     ap.add_argument("--wide", type=int, default=1, help="0 never / 1 heuristic / 2 always use the 256x128 tile")
+    ap.add_argument("--p8", type=int, default=0, help="0 never / 1 heuristic / 2 always use the 256x256 ping-pong kernel")
     a = ap.parse_args()
+    ops.call("dvlp_gemm_p8_mode", a.p8)
     ops.call("dvlp_gemm_variant", a.variant)
     ops.call("dvlp_gemm_splitk_target", a.splitk_target)
     ops.call("dvlp_gemm_ablate", a.ablate)
