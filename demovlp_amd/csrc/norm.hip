@@ -215,6 +215,90 @@ extern "C" int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x
     return dvlp_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Deferred second-stage reductions.  Every bias / LayerNorm-parameter gradient is a two-stage column sum whose second
+// stage is a ~10 us launch over a few KB; a training step has ~125 of them, each also paying a ~2 us kernel boundary.
+// With dvlp_reduce_defer() the first stage writes its partials into a caller-owned arena instead and queues the second
+// stage; dvlp_reduce_flush() runs ALL queued second stages as one launch (before the optimizer / the tail gradient
+// bucket needs them).  Only calls that pass accumulate | 2 ("result not read before the flush") are queued.
+// ------------------------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+struct RItem { const float* in; float* out; int64_t P, C, stride; int accumulate; int blk0; };
+struct RDefer {
+    std::mutex mu;
+    float* ws = nullptr; int64_t ws_floats = 0, used = 0;
+    RItem* d_items = nullptr; int64_t cap_items = 0;
+    std::vector<RItem> cur, uploaded;
+    int nblk = 0;
+};
+static RDefer g_rd;
+
+extern "C" int dvlp_reduce_defer(void* workspace, int64_t workspace_bytes, void* table, int64_t table_bytes) {
+    std::lock_guard<std::mutex> lk(g_rd.mu);
+    g_rd.ws = (float*)workspace; g_rd.ws_floats = workspace ? workspace_bytes / 4 : 0; g_rd.used = 0;
+    g_rd.d_items = (RItem*)table; g_rd.cap_items = table ? table_bytes / (int64_t)sizeof(RItem) : 0;
+    g_rd.cur.clear(); g_rd.uploaded.clear(); g_rd.nblk = 0;
+    return DVLP_OK;
+}
+// reserve `floats` of partial space for a deferrable call; nullptr: not enabled / full -> the caller reduces immediately
+static float* rd_reserve(int64_t floats, int64_t nitems) {
+    if (!g_rd.ws || g_rd.used + floats > g_rd.ws_floats || (int64_t)g_rd.cur.size() + nitems > g_rd.cap_items) return nullptr;
+    float* p = g_rd.ws + g_rd.used;
+    g_rd.used += (floats + 63) / 64 * 64;
+    return p;
+}
+static void rd_push(const float* in, float* out, int64_t P, int64_t C, int64_t stride, int accumulate) {
+    g_rd.cur.push_back(RItem{in, out, P, C, stride, accumulate, g_rd.nblk});
+    g_rd.nblk += (int)cdiv(C, 32);
+}
+
+__global__ __launch_bounds__(256) void reduce_batched_kernel(const RItem* __restrict__ items, int nitems) {
+    __shared__ float red[8][33];
+    // which item owns this block: binary search over the items' first-block prefix (<= ~10 steps, wave-uniform)
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RItem it = items[lo];
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int64_t c = (int64_t)(blockIdx.x - it.blk0) * 32 + cl;
+    float s = 0.f;
+    if (c < it.C)
+        for (int64_t p = q; p < it.P; p += 8) s += it.in[p * it.stride + c];
+    red[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && c < it.C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        it.out[c] = it.accumulate ? it.out[c] + t : t;
+    }
+}
+
+extern "C" int dvlp_reduce_flush(void* stream) {
+    std::lock_guard<std::mutex> lk(g_rd.mu);
+    if (g_rd.cur.empty()) { g_rd.used = 0; return DVLP_OK; }
+    dvlp_clear_status();
+    hipStream_t st = (hipStream_t)stream;
+    // the queue of a training step repeats exactly (same arena offsets, same destinations): upload the table only when it changed
+    bool same = g_rd.cur.size() == g_rd.uploaded.size();
+    for (size_t i = 0; same && i < g_rd.cur.size(); ++i) {
+        const RItem &a = g_rd.cur[i], &b = g_rd.uploaded[i];
+        same = a.in == b.in && a.out == b.out && a.P == b.P && a.C == b.C && a.stride == b.stride && a.accumulate == b.accumulate && a.blk0 == b.blk0;
+    }
+    if (!same) {
+        // the previous table may still be read by an earlier flush on this stream: the copy is stream-ordered behind it
+        if (hipMemcpyAsync(g_rd.d_items, g_rd.cur.data(), g_rd.cur.size() * sizeof(RItem), hipMemcpyHostToDevice, st) != hipSuccess) return DVLP_ERR_LAUNCH;
+        (void)hipStreamSynchronize(st);          // the host vector is reused right away
+        g_rd.uploaded = g_rd.cur;
+    }
+    hipLaunchKernelGGL(reduce_batched_kernel, dim3((unsigned)g_rd.nblk), dim3(256), 0, st, (const RItem*)g_rd.d_items, (int)g_rd.cur.size());
+    g_rd.cur.clear(); g_rd.used = 0; g_rd.nblk = 0;
+    return dvlp_launch_status();
+}
+
 // workspace: fp32 [(dvlp_layernorm_bwd_blocks(M) + 1) * 2 * D].  dgamma/dbeta are overwritten (accumulate=0) or added to.
 extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv(M, 4); return b < 512 ? b : 512; }
 
@@ -226,10 +310,20 @@ extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* d
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = dvlp_layernorm_bwd_blocks(M);
     dim3 grid((unsigned)nb), block(256);
+    std::unique_lock<std::mutex> lk(g_rd.mu);
+    float* dws = (accumulate & 2) ? rd_reserve(nb * 2 * D, 2) : nullptr;
+    if (dws) workspace = dws;
     if (dtype == DVLP_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, M, (int)(D / 256), (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, workspace);
     else if (dtype == DVLP_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, st, M, (int)(D / 256), (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, workspace);
     else return DVLP_ERR_DTYPE;
     // partial layout [nb][2][D]: reduce the two halves separately (stride 2D between blocks)
+    if (dws) {
+        if (dbeta == dgamma + D) rd_push(dws, dgamma, nb, 2 * D, 2 * D, accumulate & 1);
+        else { rd_push(dws, dgamma, nb, D, 2 * D, accumulate & 1); rd_push(dws + D, dbeta, nb, D, 2 * D, accumulate & 1); }
+        return dvlp_launch_status();
+    }
+    lk.unlock();
+    accumulate &= 1;
     if (dbeta == dgamma + D) {   // contiguous destination: one launch
         hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(2 * D, 32), 1), dim3(256), 0, st, nb, 2 * D, workspace, dgamma, accumulate);
     } else {
@@ -258,12 +352,21 @@ extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = dvlp_colsum_chunks(M), rows_per = cdiv(M, P);
     dim3 grid((unsigned)cdiv(N, 256), (unsigned)P, (unsigned)groups), block(256);
+    std::unique_lock<std::mutex> lk(g_rd.mu);
+    float* dws = (accumulate & 2) ? rd_reserve(groups * P * N, groups) : nullptr;
+    if (dws) workspace = dws;
+    else lk.unlock();
+    const int acc1 = accumulate & 1;
     const int64_t al = dtype == DVLP_F32 ? 4 : 8;      // elements per 16 bytes
     const int vec = (ld % al == 0) && (ostride % al == 0) && (gstride % al == 0) && ((uintptr_t)x % 16 == 0);
-    unsigned* cnt = g_colsum_counters && groups * cdiv(N, 256) <= g_colsum_ncounters ? g_colsum_counters : nullptr;
-    if (dtype == DVLP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, M, N, (const float*)x, ld, inner, ostride, gstride, rows_per, workspace, vec, cnt, out, accumulate);
-    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)x, ld, inner, ostride, gstride, rows_per, workspace, vec, cnt, out, accumulate);
+    unsigned* cnt = !dws && g_colsum_counters && groups * cdiv(N, 256) <= g_colsum_ncounters ? g_colsum_counters : nullptr;
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, M, N, (const float*)x, ld, inner, ostride, gstride, rows_per, workspace, vec, cnt, out, acc1);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)x, ld, inner, ostride, gstride, rows_per, workspace, vec, cnt, out, acc1);
     else return DVLP_ERR_DTYPE;
-    if (!cnt) hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)groups), dim3(256), 0, st, P, N, workspace, out, accumulate);
+    if (dws) {
+        for (int64_t g = 0; g < groups; ++g) rd_push(dws + g * P * N, out + g * N, P, N, N, acc1);
+        return dvlp_launch_status();
+    }
+    if (!cnt) hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)groups), dim3(256), 0, st, P, N, workspace, out, acc1);
     return dvlp_launch_status();
 }

@@ -94,8 +94,17 @@ def _wgrad(dy2d, x2d, param):
 
 
 def _bgrad(dy2d, param):
+    gb = _grad_buf(param)
     with _Side(dy2d):
-        return ops.colsum(dy2d, out=_grad_buf(param))
+        # written into the gradient arena: nobody reads it before the trainer's flush, so the final reduction may be batched
+        return ops.colsum(dy2d, out=gb, defer=gb is not None)
+
+
+def _ln_bwd(dy2d, x2d, w, b, mean, rstd, dres=None):
+    """LayerNorm backward with dgamma / dbeta going to the parameters' arena slices (deferred final reduction) when attached."""
+    gw, gb = _grad_buf(w), _grad_buf(b)
+    return ops.layernorm_bwd(dy2d, x2d, w.detach(), mean, rstd, dres=dres, out_gamma=gw, out_beta=gb,
+                             defer=gw is not None and gb is not None)
 
 
 def _into(param, value):
@@ -217,7 +226,7 @@ class VitBlockFn(torch.autograd.Function):
         df1b = _bgrad(dpre, f1b)
         df1w = _wgrad(dpre, h2, f1w)
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
-        dx1, dn2w, dn2b = ops.layernorm_bwd(dh2, x1, n2w.detach(), m2, r2, dres=dy2, out_gamma=_grad_buf(n2w), out_beta=_grad_buf(n2b))
+        dx1, dn2w, dn2b = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2)
         dpb = _bgrad(dx1, pb)
         dpw = _wgrad(dx1, att, pw)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
@@ -225,7 +234,7 @@ class VitBlockFn(torch.autograd.Function):
         dqkvb = _bgrad(dqkv, qkvb)
         dqkvw = _wgrad(dqkv, h1, qkvw)
         dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
-        dx, dn1w, dn1b = ops.layernorm_bwd(dh1, x2, n1w.detach(), m1, r1, dres=dx1, out_gamma=_grad_buf(n1w), out_beta=_grad_buf(n1b))
+        dx, dn1w, dn1b = _ln_bwd(dh1, x2, n1w, n1b, m1, r1, dres=dx1)
         return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None)
 
 
@@ -248,7 +257,7 @@ class TextEmbedFn(torch.autograd.Function):
         word, pos, lnw, lnb = ctx.params
         B, L = ids.shape
         dy2 = dy.reshape(B * L, 768).contiguous()
-        de, dg, db = ops.layernorm_bwd(dy2, e, lnw.detach(), mean, rstd, out_gamma=_grad_buf(lnw), out_beta=_grad_buf(lnb))
+        de, dg, db = _ln_bwd(dy2, e, lnw, lnb, mean, rstd)
         gv = _grad_buf(word)
         if gv is not None:
             gv.zero_()
@@ -296,14 +305,14 @@ class BertLayerFn(torch.autograd.Function):
         B, L = ctx.dims
         cd = x2.dtype
         dy2 = dy.reshape(B * L, -1).contiguous()
-        ds2, dl2w, dl2b = ops.layernorm_bwd(dy2, s2, l2w.detach(), m2, r2, out_gamma=_grad_buf(l2w), out_beta=_grad_buf(l2b))
+        ds2, dl2w, dl2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2)
         df2b = _bgrad(ds2, f2b)
         df2w = _wgrad(ds2, a, f2w)
         dpre = ops.linear_bwd_input(ds2, SHADOWS.get(f2w, cd), gelu_pre=pre)
         df1b = _bgrad(dpre, f1b)
         df1w = _wgrad(dpre, x1, f1w)
         dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
-        ds1, dl1w, dl1b = ops.layernorm_bwd(dx1, s1, l1w.detach(), m1, r1, out_gamma=_grad_buf(l1w), out_beta=_grad_buf(l1b))
+        ds1, dl1w, dl1b = _ln_bwd(dx1, s1, l1w, l1b, m1, r1)
         dob = _bgrad(ds1, ob)
         dow = _wgrad(ds1, att, ow)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))

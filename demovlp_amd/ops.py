@@ -148,14 +148,40 @@ def _ensure_colsum_counters(device):
         call("dvlp_colsum_counters", p(t), t.numel())
 
 
-def colsum(x2d, out=None, accumulate=False):
-    """fp32 [N] = sum over rows of x [M,N] (bias gradients)."""
+_DEFER = {}
+
+
+def enable_deferred_reductions(device, workspace_mb=96, max_items=4096):
+    """Let gradient column sums that are written straight into a gradient arena (``defer=True`` below) postpone their final
+    reduction to ONE batched launch at :func:`flush_reductions`.  The trainer enables this and flushes before the
+    optimizer step; without it every such call reduces immediately."""
+    key = str(device)
+    if key not in _DEFER:
+        ws = torch.empty(int(workspace_mb) << 18, device=device, dtype=torch.float32)
+        table = torch.empty(max_items * 48, device=device, dtype=torch.uint8)
+        _DEFER[key] = (ws, table)
+        call("dvlp_reduce_defer", p(ws), ws.numel() * 4, p(table), table.numel())
+
+
+def disable_deferred_reductions():
+    flush_reductions()
+    call("dvlp_reduce_defer", None, 0, None, 0)
+    _DEFER.clear()
+
+
+def flush_reductions():
+    if _DEFER:
+        call("dvlp_reduce_flush", stream())
+
+
+def colsum(x2d, out=None, accumulate=False, defer=False):
+    """fp32 [N] = sum over rows of x [M,N] (bias gradients).  ``defer``: the result is not read before flush_reductions()."""
     M, N = x2d.shape
     if out is None:
         out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     _ensure_colsum_counters(x2d.device)
     ws = _workspace("colsum", call("dvlp_colsum_chunks", M) * N, x2d.device)
-    call("dvlp_colsum", dt(x2d), M, N, p(x2d), x2d.stride(0), M, 0, 1, 0, p(out), p(ws), int(accumulate), stream())
+    call("dvlp_colsum", dt(x2d), M, N, p(x2d), x2d.stride(0), M, 0, 1, 0, p(out), p(ws), int(accumulate) | (2 if defer else 0), stream())
     return out
 
 
@@ -181,8 +207,9 @@ def layernorm_fwd(x2d, gamma, beta, eps, want_relu=False):
     return y, yr, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_beta=None):
-    """``out_gamma`` / ``out_beta``: optional fp32 destinations (e.g. gradient-arena slices); contiguous pairs reduce in one launch."""
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_beta=None, defer=False):
+    """``out_gamma`` / ``out_beta``: optional fp32 destinations (e.g. gradient-arena slices); contiguous pairs reduce in one launch.
+    ``defer``: dgamma / dbeta are not read before flush_reductions()."""
     M, D = x2d.shape
     dx = torch.empty_like(x2d)
     if out_gamma is not None and out_beta is not None:
@@ -192,7 +219,7 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_b
         dgamma, dbeta = gb[:D], gb[D:]
     ws = _workspace("ln", (call("dvlp_layernorm_bwd_blocks", M) + 1) * 2 * D, x2d.device)
     call("dvlp_layernorm_bwd", dt(x2d), M, D, p(dy2d), p(x2d), p(gamma), p(mean), p(rstd), p(dres), p(dx), p(dgamma), p(dbeta),
-         p(ws), 0, stream())
+         p(ws), 2 if defer else 0, stream())
     return dx, dgamma, dbeta
 
 

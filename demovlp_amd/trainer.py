@@ -40,14 +40,22 @@ class ParamArena:
     ALIGN = 64   # elements; keeps every slice 256-byte aligned in fp32 and 128-byte aligned in bf16
 
     def __init__(self, module: torch.nn.Module, device=None, bf16_shadow: bool = False):
-        self.params = [p for p in module.parameters()]
-        self.names = [n for n, _ in module.named_parameters()]
+        # matrices first, vectors (biases, LayerNorm parameters) last: the vectors' gradients are finished by ONE batched
+        # reduction at the end of backward (ops.flush_reductions), so they form the tail of the arena -- and of the gradient
+        # buckets -- while every bucket of weight gradients is complete, and can be all-reduced, as soon as backward passes it
+        named = list(module.named_parameters())
+        named = [kv for kv in named if kv[1].dim() >= 2] + [kv for kv in named if kv[1].dim() < 2]
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
+        self.n_matrix = sum(1 for p in self.params if p.dim() >= 2)
+        self._clean = set()       # slices known to hold zeros (tensors that never receive a gradient are zeroed once, not per step)
         device = device or self.params[0].device
         offs, o = [], 0
         for p in self.params:
             offs.append(o)
             o += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.offsets, self.total = offs, o
+        self.vec_lo = offs[self.n_matrix] if self.n_matrix < len(offs) else o
         self.flat_p = torch.zeros(o, device=device, dtype=torch.float32)
         self.flat_g = torch.zeros(o, device=device, dtype=torch.float32)
         self.flat_s = torch.zeros(o, device=device, dtype=torch.bfloat16) if bf16_shadow else None
@@ -71,6 +79,17 @@ class ParamArena:
     def slice_of(self, i):
         return self.offsets[i], self.offsets[i] + self.params[i].numel()
 
+    def zero_untouched(self, touched):
+        """Gradient slices of tensors that received no gradient this step must read as zero for the flat update.  A slice
+        zeroed once stays zero until its tensor gets a gradient again, so the ~26 grad-less tensors cost nothing per step."""
+        for i in range(len(self.params)):
+            if touched(i):
+                self._clean.discard(i)
+            elif i not in self._clean:
+                lo, hi = self.slice_of(i)
+                self.flat_g[lo:hi].zero_()
+                self._clean.add(i)
+
 
 class FusedAdamW:
     """HF AdamW (eps added to sqrt(v) before bias correction, decoupled decay, correct_bias=True) over a ParamArena."""
@@ -81,6 +100,8 @@ class FusedAdamW:
         self.m = torch.zeros_like(arena.flat_p)
         self.v = torch.zeros_like(arena.flat_p)
         self.step_count = 0
+        if arena.flat_p.is_cuda:
+            ops.enable_deferred_reductions(arena.flat_p.device)
 
     def zero_grad(self, set_to_none=True):
         for p in self.arena.params:
@@ -90,13 +111,12 @@ class FusedAdamW:
 
     def step(self, grad_scale=1.0):
         Fn.join_side_stream()          # weight gradients may still be in flight on the side stream
+        if self.arena.flat_p.is_cuda:
+            ops.flush_reductions()     # bias / LayerNorm gradients: one batched final reduction (no-op when already flushed)
         g = self.param_groups[0]
         a = self.arena
-        # tensors without a gradient this step (norm3.*, object_model.norm.*, ...) must not be updated: zero their slices
-        for i, p in enumerate(a.params):
-            if p.grad is None:
-                lo, hi = a.slice_of(i)
-                a.flat_g[lo:hi].zero_()
+        # tensors without a gradient this step (norm3.*, object_model.norm.*, ...) must not be updated: their slices read zero
+        a.zero_untouched(lambda i: a.params[i].grad is not None)
         self.step_count += 1
         ops.adamw_step(a.flat_p, a.flat_g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                        self.step_count, grad_scale, a.flat_s)
@@ -129,15 +149,19 @@ class GradReducer:
         for i, p in enumerate(arena.params):
             idxs.append(i)
             hi = arena.offsets[i] + (p.numel() + arena.ALIGN - 1) // arena.ALIGN * arena.ALIGN
-            if hi - lo >= cap:
+            # always cut at the matrix / vector boundary: vector gradients are only final after the batched reduction
+            if hi - lo >= cap or i + 1 == arena.n_matrix:
                 self.buckets.append((lo, hi, idxs))
                 lo, idxs = hi, []
         if idxs:
             self.buckets.append((lo, arena.total, idxs))
+        self.tail = set(b for b, (blo, _, _) in enumerate(self.buckets) if blo >= arena.vec_lo)   # reduced in finish() only
         self.bucket_of = {}
         for b, (_, _, idxs) in enumerate(self.buckets):
             for i in idxs:
                 self.bucket_of[i] = b
+        if arena.flat_g.is_cuda:
+            ops.enable_deferred_reductions(arena.flat_g.device)
         self.expected = None       # per bucket: set of param indices known to get gradients (learned on step 1)
         self._seen = set()
         self._pending = None
@@ -154,7 +178,7 @@ class GradReducer:
                 return
             b = self.bucket_of[i]
             self._pending[b].discard(i)
-            if not self._pending[b] and b not in self._launched:
+            if not self._pending[b] and b not in self._launched and b not in self.tail:
                 self._launch(b)
         return hook
 
@@ -182,10 +206,9 @@ class GradReducer:
         """Call after backward: zero never-touched slices, reduce what is left, wait for everything."""
         Fn.join_side_stream()
         a = self.arena
-        for i, p in enumerate(a.params):
-            if i not in self._seen:
-                lo, hi = a.slice_of(i)
-                a.flat_g[lo:hi].zero_()
+        if a.flat_g.is_cuda:
+            ops.flush_reductions()         # finishes the vector gradients of the tail bucket(s)
+        a.zero_untouched(lambda i: i in self._seen)
         if self.world > 1:
             for b in range(len(self.buckets)):
                 if b not in self._launched:
@@ -210,6 +233,8 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
     loss, global_loss, local_loss = loss_fn(global_sim, out["local_object_embeddings"], out["local_text_embeddings"],
                                             out["object_mask"], text_length, text_mask)
     loss.backward()
+    if loss.is_cuda:
+        ops.flush_reductions()
     scale = reducer.finish() if reducer is not None else 1.0
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(grad_scale=scale)

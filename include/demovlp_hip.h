@@ -67,6 +67,13 @@ int64_t dvlp_layernorm_bwd_blocks(int64_t M);
 int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace, int accumulate,
                        void* stream);
+/* Deferred second stages.  dvlp_layernorm_bwd / dvlp_colsum called with (accumulate | 2) -- "nobody reads the result before
+   the flush" -- park their partial sums in `workspace` and queue the final column reduction; dvlp_reduce_flush runs every
+   queued reduction as ONE launch (a training step otherwise pays ~125 ten-microsecond launches for them).  The table is
+   device memory for the queue (48 bytes per queued reduction).  NULL workspace disables deferral (the default): such calls
+   then reduce immediately.  The trainer flushes before the optimizer step / before reducing the tail gradient bucket. */
+int dvlp_reduce_defer(void* workspace, int64_t workspace_bytes, void* table, int64_t table_bytes);
+int dvlp_reduce_flush(void* stream);
 /* bias / table gradients: out[g][n] (+)= sum_m x_g[m][n] */
 int64_t dvlp_colsum_chunks(int64_t M);
 /* optional: `count` zeroed uint32 counters enabling the single-launch (last-workgroup-reduces) form of dvlp_colsum */

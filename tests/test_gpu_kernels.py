@@ -309,3 +309,65 @@ def test_adamw_matches_oracle():
         orc.hf_adamw_step(pr, (g * step).cpu(), mr, vr, step, lr=1e-3, eps=1e-6, weight_decay=0.01)
     assert rel(p, pr) < 1e-6 and rel(m, mr) < 1e-6 and rel(v, vr) < 1e-6
     assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("form", ["fwd", "dx", "dw"])
+def test_gemm_pingpong_race_screen(form):
+    """The 256x256 kernel orders its LDS-DMA fills against its LDS reads with counted vmcnt waits and raw barriers only:
+    screen for races by repeating launches at several K depths (1, 2, odd, long) and demanding bit-identical, correct
+    results every time."""
+    ops.call("dvlp_gemm_p8_mode", 2)
+    try:
+        for M, N, K in [(1024, 768, 64), (777, 512, 128), (2304, 1024, 448), (4096, 768, 3072)]:
+            if form == "fwd":
+                a, w = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, dtype=torch.bfloat16, seed=1)
+                ref = a.float() @ w.float().t()
+                run = lambda: ops.gemm(a, w, M, N, K)
+            elif form == "dx":
+                M8 = (M + 7) // 8 * 8
+                a, w = rnd(M8, K, dtype=torch.bfloat16), rnd(K, N, dtype=torch.bfloat16, seed=1)
+                ref = a.float() @ w.float()
+                run = lambda: ops.gemm(a, w, M8, N, K, trans_b=True, ldb=N)
+            else:
+                M8 = (M + 7) // 8 * 8
+                a, w = rnd(K, M8, dtype=torch.bfloat16), rnd(K, N, dtype=torch.bfloat16, seed=1)
+                ref = a.float().t() @ w.float()
+                run = lambda: ops.gemm(a, w, M8, N, K, trans_a=True, trans_b=True, lda=M8, ldb=N)
+            first = run().clone()
+            assert rel(first.float(), ref) < BF16_TOL
+            for _ in range(25):
+                assert torch.equal(run(), first)
+    finally:
+        ops.call("dvlp_gemm_p8_mode", P8_DEFAULT)
+
+
+def test_deferred_reductions_match_immediate():
+    """Column sums / LayerNorm parameter gradients whose final reduction is queued and run as one batched launch
+    (ops.flush_reductions) equal the immediately reduced ones bit for bit; the queue table is reused across 'steps'."""
+    torch.manual_seed(0)
+    xs = [rnd(1000, 768, dtype=torch.bfloat16), rnd(18496, 3072, dtype=torch.bfloat16, seed=3), rnd(300, 2304, dtype=torch.bfloat16, seed=4)]
+    M, D = 4000, 768
+    dy, x = rnd(M, D, dtype=torch.bfloat16, seed=5), rnd(M, D, dtype=torch.bfloat16, seed=6)
+    gamma = rnd(D, seed=7)
+    _, _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros_like(gamma), 1e-6)
+    want_cs = [ops.colsum(t) for t in xs]
+    dx0, dg0, db0 = ops.layernorm_bwd(dy, x, gamma, mean, rstd)
+    ops.enable_deferred_reductions(torch.device(DEV), workspace_mb=64)
+    try:
+        for _ in range(3):
+            outs = [torch.full((t.shape[1],), 7.0, device=DEV) for t in xs]
+            for t, o in zip(xs, outs):
+                ops.colsum(t, out=o, defer=True)
+            gb = torch.full((2 * D,), 3.0, device=DEV)
+            split_g, split_b = torch.full((D,), 1.0, device=DEV), torch.full((D,), 2.0, device=DEV)
+            dx1, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, out_gamma=gb[:D], out_beta=gb[D:], defer=True)
+            dx2, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, out_gamma=split_g, out_beta=split_b, defer=True)
+            assert float(outs[0][0]) == 7.0                      # really deferred: nothing written yet
+            ops.flush_reductions()
+            for o, w in zip(outs, want_cs):
+                assert torch.equal(o, w)
+            assert torch.equal(gb[:D], dg0) and torch.equal(gb[D:], db0)
+            assert torch.equal(split_g, dg0) and torch.equal(split_b, db0)
+            assert torch.equal(dx1, dx0) and torch.equal(dx2, dx0)
+    finally:
+        ops.disable_deferred_reductions()

@@ -160,7 +160,8 @@ def _dp_worker(rank, world, port, q):
             n2 = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 8))
             n2.load_state_dict({k: v for k, v in net.state_dict().items() if k != "unused"})
             n2(torch.full((4, 64), float(r + 1 + step))).sum().backward()
-            flat = torch.cat([p.grad.reshape(-1) for p in n2.parameters()])
+            g2 = dict(n2.named_parameters())          # arena order (matrices first, vectors last), not module order
+            flat = torch.cat([g2[n].grad.reshape(-1) for n in arena.names if n != "unused"])
             tot = flat if tot is None else tot + flat
         ref.append(tot)
     ok_red = True
