@@ -780,23 +780,15 @@ __device__ __attribute__((noinline)) void p8_store_ragged(const Epi& e, bf16* __
     }
 }
 
+// One 256 x 256 output tile at (m0, n0) over K tiles [kbeg, kbeg + 64 nk); `slab_out` non-null: raw fp32 partial (split-K).
 template <bool A_R, bool B_R>
-__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
-                                                           const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
-                                                           Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
+                                        int64_t ldb, bf16* __restrict__ C, int64_t ldc, const Epi& e, int64_t m0, int64_t n0, int64_t kbeg, int nk,
+                                        float* __restrict__ slab_out) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    int64_t tm_, tn_;
-    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
-    const int64_t m0 = tm_ * 256, n0 = tn_ * 256;
-    A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
-    if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
-    if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
-    const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
-    const int nk = (int)((kend - kbeg) / H_BK), U = 4 * nk;
+    const int U = 4 * nk;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -949,7 +941,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
     float* Ct = (float*)(smem_raw + wid * P_EPW);
     bf16x8* Rs = (bf16x8*)(smem_raw + wid * P_EPW + 32 * 68 * 4);
     bf16x8* As = Rs + 256;
-    float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
     const int ab = e.flags >> 24;                      // timing ablations (0 in production): 8 no stores, 16 no epilogue
     if (ab & 16) { if (acc[0][0][0] == 123.456f && acc[7][3][3] == 1.f) C[0] = (bf16)1.f; return; }
     if (ab & 8) M = 0;
@@ -1006,6 +997,77 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
     }
 }
 constexpr int P_EPI_LDS = 8 * (32 * 68 * 4 + 2 * 4096);
+
+template <bool A_R, bool B_R>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
+                                                           const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                           Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    int64_t tm_, tn_;
+    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
+    A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
+    if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
+    if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
+    const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
+    p8_tile<A_R, B_R>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, tm_ * 256, tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
+}
+
+// Grouped weight gradients: up to P8G_MAX independent dW_p = dY_p^T X_p products (all form R x form R, fp32 out) in ONE
+// launch.  A layer's weight gradients are 9-36 output tiles each -- far too few to fill 256 CUs one at a time without
+// splitting K 7-28 ways, which costs ~65 MB of fp32 slabs per product.  Together they are ~110 tiles, so a 2-3 way split
+// fills the chip and the slab traffic drops ~4x.  Block ranges of the problems start at multiples of 8 so that the
+// XCD-aware tile order stays valid inside each problem.
+constexpr int P8G_MAX = 8;
+struct P8Group {
+    int count;
+    int blk0[P8G_MAX + 1];                 // first block of each problem (multiples of 8), blk0[count] = grid size
+    int ntn[P8G_MAX], tiles[P8G_MAX], S[P8G_MAX];
+    int64_t M[P8G_MAX], N[P8G_MAX], K[P8G_MAX], lda[P8G_MAX], ldb[P8G_MAX], kchunk[P8G_MAX];
+    const bf16* A[P8G_MAX];
+    const bf16* B[P8G_MAX];
+    float* C[P8G_MAX];                     // final fp32 destination (S == 1: written directly)
+    float* slab[P8G_MAX];                  // S > 1: [S][M][N] partials
+};
+__global__ __launch_bounds__(512) void gemm_bf16_p8_group_kernel(P8Group g, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < P8G_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.blk0[i]) p = i;
+    const int local = (int)blockIdx.x - g.blk0[p];
+    const int nblk = g.tiles[p] * g.S[p];
+    if (local >= nblk) return;                                  // padding block
+    const int64_t wg = xcd_remap(local, nblk);                  // blk0 is a multiple of 8, so local % 8 still names the XCD
+    const int z = (int)(wg / g.tiles[p]);
+    int64_t tm_, tn_;
+    tile_of(wg % g.tiles[p], g.tiles[p] / g.ntn[p], g.ntn[p], tm_, tn_);
+    const int64_t kbeg = z * g.kchunk[p], kend = kbeg + g.kchunk[p] < g.K[p] ? kbeg + g.kchunk[p] : g.K[p];
+    Epi e{nullptr, nullptr, nullptr, 0, 0, flags | EPI_OUT_F32, 1.0f, 0, 0, 0, 0, 0, 1};
+    e.vec = (g.N[p] % 4 == 0) ? 1 : 0;
+    float* slab_out = g.S[p] > 1 ? g.slab[p] + (int64_t)z * g.M[p] * g.N[p] : nullptr;
+    p8_tile<true, true>(smem_raw, g.M[p], g.N[p], g.A[p], g.lda[p], g.B[p], g.ldb[p], (bf16*)g.C[p], g.N[p], e, tm_ * 256, tn_ * 256, kbeg,
+                        (int)((kend - kbeg) / H_BK), slab_out);
+}
+// sums the slabs of every split problem of a group into its fp32 destination (float4 per thread)
+struct P8GroupReduce { int count; int blk0[P8G_MAX + 1]; int S[P8G_MAX]; int64_t MN[P8G_MAX]; const float* slab[P8G_MAX]; float* C[P8G_MAX]; };
+__global__ __launch_bounds__(256) void p8_group_reduce_kernel(P8GroupReduce g, int accumulate) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < P8G_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.blk0[i]) p = i;
+    const int64_t i4 = ((int64_t)((int)blockIdx.x - g.blk0[p]) * 256 + threadIdx.x) * 4;
+    if (i4 >= g.MN[p]) return;
+    float4 s = *(const float4*)(g.slab[p] + i4);
+    for (int k = 1; k < g.S[p]; ++k) {
+        const float4 v = *(const float4*)(g.slab[p] + (int64_t)k * g.MN[p] + i4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) {
+        const float4 c = *(const float4*)(g.C[p] + i4);
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+    }
+    *(float4*)(g.C[p] + i4) = s;
+}
 constexpr int P_LDS_TOTAL = P_EPI_LDS > P_LDS ? P_EPI_LDS : P_LDS;      // K-loop buffers / epilogue staging
 
 // second stage of a split-K GEMM: sum the S fp32 slabs of one output and apply the epilogue (8 columns per thread)
@@ -1100,7 +1162,7 @@ extern "C" int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t*
         if (report) {
             char key[160];
             snprintf(key, sizeof key, "%s M=%6lld N=%5lld K=%6lld b=%4lld epi=%2d kern=%s", r.form == 0 ? "KK" : r.form == 1 ? "KR" : r.form == 3 ? "RR" : "RK",
-                     (long long)r.M, (long long)r.N, (long long)r.K, (long long)r.batch, r.flags, r.kern == 2 ? "p8  " : r.kern == 1 ? "g128" : "reg ");
+                     (long long)r.M, (long long)r.N, (long long)r.K, (long long)r.batch, r.flags, r.kern == 3 ? "p8g " : r.kern == 2 ? "p8  " : r.kern == 1 ? "g128" : "reg ");
             Agg& a = table[key];
             a.ms += t; a.fl += r.flops; a.n += 1;
         }
@@ -1230,3 +1292,94 @@ extern "C" int dvlp_gemm(int dtype, int transA, int transB, int64_t M, int64_t N
     return dvlp_gemm_batched(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldres, aux, ldaux, flags, alpha, 1, 0, 0,
                              0, 0, 0, stream);
 }
+
+// Weight gradients of several linears in one go: dW_p[M_p, N_p] (fp32, contiguous) (+)= dY_p[K_p, M_p]^T X_p[K_p, N_p].
+// bf16 operands that suit the 256 x 256 kernel run as ONE grouped launch (+ one slab reduction); anything else falls back
+// to per-problem dvlp_gemm calls with identical results.
+extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
+                                  const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate,
+                                  void* stream) {
+    if (count <= 0) return DVLP_OK;
+    const int flags = EPI_OUT_F32 | (accumulate ? EPI_ACCUM : 0);
+    bool group_ok = dtype == DVLP_BF16 && g_p8_mode != 0 && g_use_glds && count <= P8G_MAX && count > 1;
+    int64_t T = 0;
+    for (int p = 0; group_ok && p < count; ++p) {
+        group_ok = M[p] >= 256 && N[p] >= 256 && M[p] % 8 == 0 && N[p] % 8 == 0 && K[p] % H_BK == 0 && K[p] >= 1024 && ld_dy[p] % 8 == 0 &&
+                   ld_x[p] % 8 == 0 && (uintptr_t)dY[p] % 16 == 0 && (uintptr_t)X[p] % 16 == 0 && (uintptr_t)dW[p] % 16 == 0;
+        T += cdiv(M[p], 256) * cdiv(N[p], 256);
+    }
+    const WsEntry wse = ws_for(stream);
+    if (!group_ok || T > 256 || !wse.ptr) {
+        for (int p = 0; p < count; ++p) {
+            const int rc = dvlp_gemm(dtype, 1, 1, M[p], N[p], K[p], dY[p], ld_dy[p], X[p], ld_x[p], dW[p], N[p], nullptr, nullptr, 0, nullptr, 0,
+                                     flags, 1.0f, stream);
+            if (rc != DVLP_OK) return rc;
+        }
+        return DVLP_OK;
+    }
+    dvlp_clear_status();
+    hipStream_t st = (hipStream_t)stream;
+    P8Group g{};
+    g.count = count;
+    int64_t S[P8G_MAX], tiles[P8G_MAX], total = 0;
+    for (int p = 0; p < count; ++p) {
+        tiles[p] = cdiv(M[p], 256) * cdiv(N[p], 256);
+        S[p] = 256 / T > 0 ? 256 / T : 1;
+        if (S[p] > K[p] / 256) S[p] = K[p] / 256;
+        total += tiles[p] * S[p];
+    }
+    // spend the remaining CUs on the problems whose blocks run longest
+    for (;;) {
+        int best = -1;
+        for (int p = 0; p < count; ++p)
+            if (total + tiles[p] <= 256 && S[p] < K[p] / 256 && (best < 0 || K[p] / S[p] > K[best] / S[best])) best = p;
+        if (best < 0) break;
+        S[best] += 1; total += tiles[best];
+    }
+    // slabs for every split problem must fit the split-K workspace; otherwise split less
+    for (;;) {
+        int64_t need = 0;
+        for (int p = 0; p < count; ++p) if (S[p] > 1) need += S[p] * M[p] * N[p] * 4;
+        if (need <= wse.bytes) break;
+        int worst = 0;
+        for (int p = 1; p < count; ++p) if (S[p] * M[p] * N[p] > S[worst] * M[worst] * N[worst]) worst = p;
+        if (S[worst] == 1) break;
+        S[worst] -= 1;
+    }
+    P8GroupReduce r{};
+    int blk = 0, rblk = 0, nred = 0;
+    float* slab = wse.ptr;
+    double flops = 0;
+    for (int p = 0; p < count; ++p) {
+        const int64_t kchunk = cdiv(cdiv(K[p], S[p]), H_BK) * H_BK;
+        S[p] = cdiv(K[p], kchunk);
+        g.blk0[p] = blk;
+        g.ntn[p] = (int)cdiv(N[p], 256); g.tiles[p] = (int)tiles[p]; g.S[p] = (int)S[p];
+        g.M[p] = M[p]; g.N[p] = N[p]; g.K[p] = K[p]; g.lda[p] = ld_dy[p]; g.ldb[p] = ld_x[p]; g.kchunk[p] = kchunk;
+        g.A[p] = (const bf16*)dY[p]; g.B[p] = (const bf16*)X[p]; g.C[p] = (float*)dW[p];
+        g.slab[p] = S[p] > 1 ? slab : nullptr;
+        blk += (int)((tiles[p] * S[p] + 7) / 8 * 8);
+        flops += 2.0 * M[p] * N[p] * K[p];
+        if (S[p] > 1) {
+            r.blk0[nred] = rblk; r.S[nred] = (int)S[p]; r.MN[nred] = M[p] * N[p]; r.slab[nred] = slab; r.C[nred] = (float*)dW[p];
+            rblk += (int)cdiv(M[p] * N[p], 1024);
+            slab += S[p] * M[p] * N[p];
+            ++nred;
+        }
+    }
+    g.blk0[count] = blk;
+    r.count = nred; r.blk0[nred] = rblk;
+    ProfRec rec{};
+    if (g_prof) {
+        (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);
+        rec.flops = flops; rec.M = T; rec.N = count; rec.K = K[0]; rec.batch = 1; rec.form = 3; rec.flags = flags; rec.kern = 3;
+        (void)hipEventRecord(rec.a, st);
+    }
+    { static bool once = false; if (!once) { once = true;
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } }
+    hipLaunchKernelGGL(gemm_bf16_p8_group_kernel, dim3((unsigned)blk), dim3(512), (size_t)P_LDS_TOTAL, st, g, (accumulate ? EPI_ACCUM : 0) | (g_ablate << 24));
+    if (nred) hipLaunchKernelGGL(p8_group_reduce_kernel, dim3((unsigned)rblk), dim3(256), 0, st, r, accumulate);
+    if (g_prof) { (void)hipEventRecord(rec.b, st); g_recs.push_back(rec); }
+    return dvlp_launch_status();
+}
+

@@ -93,6 +93,12 @@ def _wgrad(dy2d, x2d, param):
         return ops.linear_bwd_weight(dy2d, x2d, out=_grad_buf(param))
 
 
+def _wgrad_group(items):
+    """Weight gradients of one layer [(dy2d, x2d, param), ...] as one grouped launch (ops.wgrad_grouped)."""
+    with _Side(*[t for it in items for t in it[:2]], level=2):
+        return ops.wgrad_grouped([(dy2d, x2d, _grad_buf(param)) for dy2d, x2d, param in items])
+
+
 def _bgrad(dy2d, param):
     gb = _grad_buf(param)
     with _Side(dy2d):
@@ -221,19 +227,17 @@ class VitBlockFn(torch.autograd.Function):
         cd = x2.dtype
         dy2 = dy.reshape(B * N, -1).contiguous()
         df2b = _bgrad(dy2, f2b)
-        df2w = _wgrad(dy2, a, f2w)
         dpre = ops.linear_bwd_input(dy2, SHADOWS.get(f2w, cd), gelu_pre=pre)
         df1b = _bgrad(dpre, f1b)
-        df1w = _wgrad(dpre, h2, f1w)
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
         dx1, dn2w, dn2b = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2)
         dpb = _bgrad(dx1, pb)
-        dpw = _wgrad(dx1, att, pw)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
         dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R)
         dqkvb = _bgrad(dqkv, qkvb)
-        dqkvw = _wgrad(dqkv, h1, qkvw)
         dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
+        # the four weight gradients of the block (9-36 output tiles each, K = B*N tokens) as ONE grouped GEMM
+        df2w, df1w, dpw, dqkvw = _wgrad_group([(dy2, a, f2w), (dpre, h2, f1w), (dx1, att, pw), (dqkv, h1, qkvw)])
         dx, dn1w, dn1b = _ln_bwd(dh1, x2, n1w, n1b, m1, r1, dres=dx1)
         return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None)
 
@@ -307,18 +311,15 @@ class BertLayerFn(torch.autograd.Function):
         dy2 = dy.reshape(B * L, -1).contiguous()
         ds2, dl2w, dl2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2)
         df2b = _bgrad(ds2, f2b)
-        df2w = _wgrad(ds2, a, f2w)
         dpre = ops.linear_bwd_input(ds2, SHADOWS.get(f2w, cd), gelu_pre=pre)
         df1b = _bgrad(dpre, f1b)
-        df1w = _wgrad(dpre, x1, f1w)
         dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
         ds1, dl1w, dl1b = _ln_bwd(dx1, s1, l1w, l1b, m1, r1)
         dob = _bgrad(ds1, ob)
-        dow = _wgrad(ds1, att, ow)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))
         dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, datt, B, L)
         dqb, dkb, dvb = _bgrad(dq, qb), _bgrad(dk, kb), _bgrad(dv, vb)
-        dqw, dkw, dvw = _wgrad(dq, x2, qw), _wgrad(dk, x2, kw), _wgrad(dv, x2, vw)
+        df2w, df1w, dow, dqw, dkw, dvw = _wgrad_group([(ds2, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dq, x2, qw), (dk, x2, kw), (dv, x2, vw)])
         dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
         ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
         ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)

@@ -118,6 +118,32 @@ def linear_bwd_weight(dy2d, x2d, out=None):
     return gemm(dy2d, x2d, N, K, M, trans_a=True, trans_b=True, lda=N, ldb=K, out=out, out_f32=True)
 
 
+def wgrad_grouped(problems):
+    """[(dy2d [T, N_p], x2d [T, K_p], out fp32 [N_p, K_p] or None)] -> list of dW_p = dy_p^T x_p (fp32).  One grouped launch for
+    bf16 operands that suit the 256 x 256 GEMM kernel (a transformer layer's weight gradients), else per-problem GEMMs."""
+    n = len(problems)
+    outs = []
+    I64, VP = ctypes.c_int64 * n, ctypes.c_void_p * n
+    Ms, Ns, Ks, lda, ldb = I64(), I64(), I64(), I64(), I64()
+    A, Bp, C = VP(), VP(), VP()
+    d = dt(problems[0][0])
+    if d == BF16:
+        ensure_gemm_workspace(problems[0][0].device)
+    for i, (dy2d, x2d, out) in enumerate(problems):
+        T, N = dy2d.shape
+        K = x2d.shape[1]
+        assert x2d.shape[0] == T and dt(dy2d) == d and dt(x2d) == d and dy2d.stride(1) == 1 and x2d.stride(1) == 1
+        if out is None:
+            out = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
+        assert out.is_contiguous() and out.dtype == torch.float32
+        outs.append(out)
+        Ms[i], Ns[i], Ks[i], lda[i], ldb[i] = N, K, T, dy2d.stride(0), x2d.stride(0)
+        A[i], Bp[i], C[i] = dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr()
+    call("dvlp_wgrad_grouped", d, n, ctypes.addressof(Ms), ctypes.addressof(Ns), ctypes.addressof(Ks), ctypes.addressof(A), ctypes.addressof(lda),
+         ctypes.addressof(Bp), ctypes.addressof(ldb), ctypes.addressof(C), 0, stream())
+    return outs
+
+
 _WS = {}
 
 

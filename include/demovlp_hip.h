@@ -41,6 +41,12 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
                       const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
                       void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
                       int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream);
+/* The weight gradients of `count` linears at once: dW_p[M_p, N_p] (fp32, contiguous) (+)= dY_p[K_p, M_p]^T X_p[K_p, N_p], i.e.
+   count calls of dvlp_gemm(transA=1, transB=1, fp32 out) -- the K = batch*tokens reductions of one transformer layer
+   (reference: autograd of the nn.Linear modules in object_transformer.py:100-196 and DistilBERT's TransformerBlock).  Arguments are
+   host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
+int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
+                       const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
 /* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
 int dvlp_gemm_variant(int use_lds_dma);
 /* TIMING-ONLY ablation of the LDS-DMA kernel's K loop (1 no DMA, 2 no fragment reads, 4 no MFMA); 0 in production */

@@ -371,3 +371,21 @@ def test_deferred_reductions_match_immediate():
             assert torch.equal(dx1, dx0) and torch.equal(dx2, dx0)
     finally:
         ops.disable_deferred_reductions()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_grouped_matches_single(dtype):
+    """dvlp_wgrad_grouped (one grouped 256x256 launch + one slab reduction in bf16) against per-problem dW GEMMs and fp32 torch."""
+    T = 4160
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (256, 768), (768, 264)]
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy, x = rnd(T, N, dtype=dtype, seed=i), rnd(T, K, dtype=dtype, seed=10 + i)
+        probs.append((dy, x, None))
+        refs.append(dy.float().t() @ x.float())
+    for sel in ([0, 1, 2, 3], [0, 1, 2, 3, 4, 5], [2], [4, 5]):
+        outs = ops.wgrad_grouped([probs[i] for i in sel])
+        for o, i in zip(outs, sel):
+            single = ops.linear_bwd_weight(probs[i][0], probs[i][1])
+            assert rel(o, refs[i]) < tol(dtype), (sel, i)
+            assert rel(o, single) < 1e-5, (sel, i)          # same products, possibly a different K split
