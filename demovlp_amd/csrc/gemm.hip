@@ -743,6 +743,32 @@ __device__ __forceinline__ void g_tr4(bf16x4 (&lo)[2], bf16x4 (&hi)[2], unsigned
 __device__ __forceinline__ void g_wait4(bf16x4 (&lo)[2], bf16x4 (&hi)[2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]) :: "memory");
 }
+// the same reads with the unit / k-step displacement as an IMMEDIATE offset: the address registers then stay the 4 (or 2)
+// per-lane fragment offsets (per buffer parity) instead of one hoisted VGPR per (parity, unit, k-step, fragment) combination
+template <int OFF>
+__device__ __forceinline__ void g_tr8i(bf16x4 (&lo)[4], bf16x4 (&hi)[4], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%13"
+        : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "i"(OFF), "i"(OFF + 1024) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void g_tr4i(bf16x4 (&lo)[2], bf16x4 (&hi)[2], unsigned a0, unsigned a1) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4 offset:%6\n\t"
+        "ds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+        "ds_read_b64_tr_b16 %2, %5 offset:%6\n\t"
+        "ds_read_b64_tr_b16 %3, %5 offset:%7"
+        : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1])
+        : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 1024) : "memory");
+}
 template <int N> __device__ __forceinline__ void p_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // allow `units` (<= 4) staged units = 2 * units LDS-DMA instructions of this wave to stay in flight
 __device__ __forceinline__ void p_wait_units(int units) {
@@ -846,28 +872,41 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     for (int j = 0; j < 2; ++j)
         bR[j] = (unsigned)((8 * g + qq) * 256 + (((4 * wc + 2 * j + (pp >> 1)) ^ ((((g & 1) << 2) + qq) << 1)) << 4) + ((pp & 1) << 3));
     const unsigned lds0 = (unsigned)(uintptr_t)smem_raw;
+    // transposing reads take (address register + immediate): one register set per buffer parity (the 64 KiB between the
+    // two K-tile buffers does not fit the 16-bit offset field)
+    unsigned aRp[2][4], bRp[2][2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aRp[par][i] = lds0 + par * P_BUF + aR[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bRp[par][j] = lds0 + par * P_BUF + bR[j];
+    }
 
     bf16x8 aF[2][4], bL[2][2], bH[2][2];                      // [k-step][fragment]
     bf16x4 alo[2][4], ahi[2][4], bllo[2][2], blhi[2][2], bhlo[2][2], bhhi[2][2];
-    auto read_a = [&](int unit_off) {
+    auto read_a = [&](auto par_, auto kind_) {
+        constexpr int PAR = decltype(par_)::value, KOFF = decltype(kind_)::value * P_UNIT;
+        if constexpr (A_R) {
+            g_tr8i<KOFF>(alo[0], ahi[0], aRp[PAR][0], aRp[PAR][1], aRp[PAR][2], aRp[PAR][3]);
+            g_tr8i<KOFF + 8192>(alo[1], ahi[1], aRp[PAR][0], aRp[PAR][1], aRp[PAR][2], aRp[PAR][3]);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (A_R) g_tr8<1024>(alo[s], ahi[s], lds0 + unit_off + aR[0] + s * 8192, lds0 + unit_off + aR[1] + s * 8192,
-                                 lds0 + unit_off + aR[2] + s * 8192, lds0 + unit_off + aR[3] + s * 8192);
-            else {
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) aF[s][i] = *(const bf16x8*)(smem_raw + unit_off + aK[s] + i * 2048);
-            }
+                for (int i = 0; i < 4; ++i) aF[s][i] = *(const bf16x8*)(smem_raw + PAR * P_BUF + KOFF + aK[s] + i * 2048);
         }
     };
-    auto read_b = [&](int unit_off, bf16x8 (&bf)[2][2], bf16x4 (&lo)[2][2], bf16x4 (&hi)[2][2]) {
+    auto read_b = [&](auto par_, auto kind_, bf16x8 (&bf)[2][2], bf16x4 (&lo)[2][2], bf16x4 (&hi)[2][2]) {
+        constexpr int PAR = decltype(par_)::value, KOFF = decltype(kind_)::value * P_UNIT;
+        if constexpr (B_R) {
+            g_tr4i<KOFF>(lo[0], hi[0], bRp[PAR][0], bRp[PAR][1]);
+            g_tr4i<KOFF + 8192>(lo[1], hi[1], bRp[PAR][0], bRp[PAR][1]);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (B_R) g_tr4<1024>(lo[s], hi[s], lds0 + unit_off + bR[0] + s * 8192, lds0 + unit_off + bR[1] + s * 8192);
-            else {
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[s][j] = *(const bf16x8*)(smem_raw + unit_off + bK[s] + j * 2048);
-            }
+                for (int j = 0; j < 2; ++j) bf[s][j] = *(const bf16x8*)(smem_raw + PAR * P_BUF + KOFF + bK[s] + j * 2048);
         }
     };
     auto land_a = [&]() {
@@ -891,12 +930,14 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
     };
 
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     auto phase = [&](auto q_, auto par_, int P) {
         constexpr int Q = decltype(q_)::value, PAR = decltype(par_)::value;
         // ---- load segment: fragment reads of this phase, one unit of prefetch, counted wait for what the NEXT phase reads
-        if constexpr (Q == 0) { read_b(PAR * P_BUF + 1 * P_UNIT, bL, bllo, blhi); read_a(PAR * P_BUF + 0 * P_UNIT); }
-        if constexpr (Q == 1) read_b(PAR * P_BUF + 2 * P_UNIT, bH, bhlo, bhhi);
-        if constexpr (Q == 2) read_a(PAR * P_BUF + 3 * P_UNIT);
+        if constexpr (Q == 0) { read_b(par_, I1{}, bL, bllo, blhi); read_a(par_, I0{}); }
+        if constexpr (Q == 1) read_b(par_, I2{}, bH, bhlo, bhhi);
+        if constexpr (Q == 2) read_a(par_, I3{});
         if (P + 6 < U) stage(std::integral_constant<int, (Q + 2) & 3>{}, Q < 2 ? (PAR ^ 1) : PAR);
         if constexpr (Q != 2) p_wait_units(U - 3 - P);
         __builtin_amdgcn_s_barrier();
@@ -918,8 +959,6 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     };
 
     // prologue: units 0..5 (tile 0 and the first half of tile 1), wait for units 0 and 1
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0);
     if (nk > 1) { stage(I0{}, 1); stage(I1{}, 1); p_vmcnt<8>(); }
     else p_vmcnt<4>();
