@@ -300,7 +300,7 @@ extern "C" int dvlp_reduce_flush(void* stream) {
 }
 
 // workspace: fp32 [(dvlp_layernorm_bwd_blocks(M) + 1) * 2 * D].  dgamma/dbeta are overwritten (accumulate=0) or added to.
-extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv(M, 4); return b < 512 ? b : 512; }
+extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv(M, 4); return b < 1024 ? b : 1024; }
 
 extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace,

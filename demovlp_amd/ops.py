@@ -177,7 +177,7 @@ def _ensure_colsum_counters(device):
 _DEFER = {}
 
 
-def enable_deferred_reductions(device, workspace_mb=96, max_items=4096):
+def enable_deferred_reductions(device, workspace_mb=384, max_items=4096):
     """Let gradient column sums that are written straight into a gradient arena (``defer=True`` below) postpone their final
     reduction to ONE batched launch at :func:`flush_reductions`.  The trainer enables this and flushes before the
     optimizer step; without it every such call reduces immediately."""
