@@ -185,18 +185,21 @@ def main():
         }
         if gemm_n:
             # HBM-side traffic per launch of the GEMM family cannot be self-measured from inside the process: it comes from
-            # the committed rocprofv3 PMC passes of this same command (profiles/r1_gemm_hbm_traffic_pmc.json)
+            # the committed rocprofv3 PMC passes of this same command (profiles/r1_final_gemm_hbm_traffic_pmc.json)
             traffic = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_gemm_hbm_traffic_pmc.json")))
-                if a.dtype == "bf16" and B == 64 and F == 8 and R == 36:
-                    traffic = round(tj["gemm_family_traffic_bytes_per_launch"])
-            except Exception:
-                pass
+            for fn in ("r1_final_gemm_hbm_traffic_pmc.json", "r1_gemm_hbm_traffic_pmc.json"):
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    if a.dtype == "bf16" and B == 64 and F == 8 and R == 36:
+                        traffic = round(tj["gemm_family_traffic_bytes_per_launch"])
+                    break
+                except Exception:
+                    pass
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline PMC pass)",
-                               "algorithmic_flops_per_launch": round(gemm_flops / gemm_n), "kernel": "gemm_%s_kernel (all forms)" % ("bf16" if a.dtype == "bf16" else "f32"),
+                               "algorithmic_flops_per_launch": round(gemm_flops / gemm_n), "kernel": ("gemm_bf16_p8_kernel / gemm_bf16_p8_group_kernel / gemm_bf16_glds_kernel (all operand forms, incl. their split-K reductions)"
+                                          if a.dtype == "bf16" else "gemm_f32_kernel (all forms)"),
                                "launches_per_step": gemm_n // a.steps, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
                                "gemm_share_of_step": round(gemm_ms * 1e-3 / elapsed, 3)}
         if world == 1 and not a.no_cpu_baseline:

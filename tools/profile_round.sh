@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): the default bench line, the rocprofv3 kernel trace of the same command, and the two
+# PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, kernel-trace only) the roofline `traffic` figure is derived from.
+# Outputs land in gpurun_out/prof_round/; tools/make_profiles.py turns them into the committed summaries under profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/prof_round
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/fetch.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/write.err
+# keep what travels back small: the per-dispatch traces are large
+for d in trace fetch write; do find $O/$d -name "*kernel_trace.csv" -size +20M -delete; done
+ls -la $O $O/trace $O/fetch $O/write
