@@ -9,6 +9,8 @@ Weight gradients are produced in fp32 straight from the MFMA epilogue.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -94,9 +96,40 @@ def _wgrad(dy2d, x2d, param):
 
 
 def _wgrad_group(items):
-    """Weight gradients of one layer [(dy2d, x2d, param), ...] as one grouped launch (ops.wgrad_grouped)."""
+    """Weight gradients of one layer [(dy2d, x2d, param | fp32 destination tensor), ...] as one grouped launch (ops.wgrad_grouped)."""
     with _Side(*[t for it in items for t in it[:2]], level=2):
-        return ops.wgrad_grouped([(dy2d, x2d, _grad_buf(param)) for dy2d, x2d, param in items])
+        return ops.wgrad_grouped([(dy2d, x2d, _grad_buf(dst) if isinstance(dst, torch.nn.Parameter) else dst) for dy2d, x2d, dst in items])
+
+
+FUSE_TEXT_QKV = os.environ.get("DVLP_NO_FUSED_QKV") is None      # developer switch for A/B timing
+
+
+def _stacked(ts):
+    """If equally shaped tensors sit back to back in one allocation (parameter-arena order), one [n*rows, ...] view of them."""
+    a = ts[0]
+    if any(t is None or t.shape != a.shape or t.dtype != a.dtype or not t.is_contiguous() for t in ts):
+        return None
+    step = a.numel() * a.element_size()
+    same = all(t.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() and t.data_ptr() == a.data_ptr() + i * step for i, t in enumerate(ts))
+    if not same:
+        return None
+    shape = (len(ts) * a.shape[0],) + tuple(a.shape[1:])
+    stride = tuple(a.stride())
+    return torch.as_strided(a, shape, stride)
+
+
+def _fused_qkv(qw, qb, kw, kb, vw, vb, cd):
+    """DistilBERT keeps q_lin / k_lin / v_lin as separate modules; inside a ParamArena their weights (and biases, gradients,
+    bf16 shadows) are adjacent, so the three projections run as ONE [2304, 768] linear.  None when they are not adjacent."""
+    if not FUSE_TEXT_QKV:
+        return None
+    W = _stacked([SHADOWS.get(w, cd) for w in (qw, kw, vw)])
+    b = _stacked([t.detach() for t in (qb, kb, vb)])
+    gW = _stacked([getattr(w, "_dvlp_grad_view", None) for w in (qw, kw, vw)])
+    gb = _stacked([getattr(t, "_dvlp_grad_view", None) for t in (qb, kb, vb)])
+    if W is None or b is None or gW is None or gb is None:
+        return None
+    return W, b, gW, gb
 
 
 def _bgrad(dy2d, param):
@@ -184,7 +217,8 @@ class ObjectPrologueFn(torch.autograd.Function):
         dtok = ops.embed_unassemble(dx, B, F, R)
         dWo = _wgrad(dtok, feat, Wo)
         dbo = _bgrad(dtok, bo)
-        dbp = _into(bp, dbo.clone())                      # same sum: both biases are added to every region token
+        dbp = _bgrad(dtok, bp)                            # same sum (both biases are added to every region token), but dbo may
+                                                          # still be a deferred reduction here: it cannot be read and copied
         dWp = ops.box_wgrad(dtok, box, out=_grad_buf(Wp))
         # temporal[f] = sum over (b, r) of dtok[b, f, r, :]
         gt = _grad_buf(temporal) if temporal.shape[1] == F else None
@@ -282,10 +316,17 @@ class BertLayerFn(torch.autograd.Function):
         B, L, D = x.shape
         cd = x.dtype
         x2 = x.reshape(B * L, D)
-        q = ops.linear_fwd(x2, SHADOWS.get(qw, cd), qb.detach())
-        k = ops.linear_fwd(x2, SHADOWS.get(kw, cd), kb.detach())
-        v = ops.linear_fwd(x2, SHADOWS.get(vw, cd), vb.detach())
-        att = ops.full_attention_fwd(q, k, v, addmask, B, L)
+        fused = _fused_qkv(qw, qb, kw, kb, vw, vb, cd)
+        if fused is not None:
+            qkv = ops.linear_fwd(x2, fused[0], fused[1])                          # [B*L, 2304] = q | k | v
+            q, k, v = qkv[:, :768], qkv[:, 768:1536], qkv[:, 1536:]
+            att = ops.full_attention_fwd(q, k, v, addmask, B, L, ld=2304)
+        else:
+            q = ops.linear_fwd(x2, SHADOWS.get(qw, cd), qb.detach())
+            k = ops.linear_fwd(x2, SHADOWS.get(kw, cd), kb.detach())
+            v = ops.linear_fwd(x2, SHADOWS.get(vw, cd), vb.detach())
+            att = ops.full_attention_fwd(q, k, v, addmask, B, L)
+        ctx.fused = fused is not None
         s1 = ops.linear_fwd(att, SHADOWS.get(ow, cd), ob.detach(), res=x2)
         x1, _, m1, r1 = ops.layernorm_fwd(s1, l1w.detach(), l1b.detach(), 1e-12)
         pre = torch.empty((B * L, f1w.shape[0]), device=x.device, dtype=cd)
@@ -317,12 +358,23 @@ class BertLayerFn(torch.autograd.Function):
         ds1, dl1w, dl1b = _ln_bwd(dx1, s1, l1w, l1b, m1, r1)
         dob = _bgrad(ds1, ob)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))
-        dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, datt, B, L)
-        dqb, dkb, dvb = _bgrad(dq, qb), _bgrad(dk, kb), _bgrad(dv, vb)
-        df2w, df1w, dow, dqw, dkw, dvw = _wgrad_group([(ds2, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dq, x2, qw), (dk, x2, kw), (dv, x2, vw)])
-        dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
-        ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
-        ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)
+        fused = _fused_qkv(qw, qb, kw, kb, vw, vb, cd) if ctx.fused else None
+        if fused is not None:
+            W, _, gW, gb = fused
+            dqkv = torch.empty((B * L, 2304), device=q.device, dtype=cd)
+            ops.full_attention_bwd(q, k, v, addmask, datt, B, L, ld=2304, out=(dqkv[:, :768], dqkv[:, 768:1536], dqkv[:, 1536:]), ld_out=2304)
+            with _Side(dqkv):
+                ops.colsum(dqkv, out=gb, defer=True)
+            df2w, df1w, dow, _ = _wgrad_group([(ds2, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dqkv, x2, gW)])
+            dqw, dkw, dvw, dqb, dkb, dvb = (_grad_buf(t) for t in (qw, kw, vw, qb, kb, vb))      # slices of the fused gradients
+            dx = ops.linear_bwd_input(dqkv, W, res=ds1)
+        else:
+            dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, datt, B, L)
+            dqb, dkb, dvb = _bgrad(dq, qb), _bgrad(dk, kb), _bgrad(dv, vb)
+            df2w, df1w, dow, dqw, dkw, dvw = _wgrad_group([(ds2, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dq, x2, qw), (dk, x2, kw), (dv, x2, vw)])
+            dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
+            ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
+            ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)
         return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, dl1w, dl1b, df1w, df1b, df2w, df2b, dl2w, dl2b, None)
 
 

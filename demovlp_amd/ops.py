@@ -279,16 +279,20 @@ def space_attention_bwd(qkv, addmask, dout, B, F, R):
     return dqkv
 
 
-def full_attention_fwd(q, k, v, addmask, B, L):
+def full_attention_fwd(q, k, v, addmask, B, L, ld=768):
+    """``ld``: row stride of q / k / v (2304 when they are the three column blocks of one packed projection)."""
     out = torch.empty((B * L, 768), device=q.device, dtype=q.dtype)
-    call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), 768, p(addmask), p(out), 768, SCALE, stream())
+    call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(out), 768, SCALE, stream())
     return out
 
 
-def full_attention_bwd(q, k, v, addmask, dout, B, L):
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    call("dvlp_attention_bwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), 768, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
-         768, None, SCALE, stream())
+def full_attention_bwd(q, k, v, addmask, dout, B, L, ld=768, out=None, ld_out=768):
+    if out is None:
+        dq, dk, dv = (torch.empty((B * L, 768), device=q.device, dtype=q.dtype) for _ in range(3))
+    else:
+        dq, dk, dv = out
+    call("dvlp_attention_bwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
+         ld_out, None, SCALE, stream())
     return dq, dk, dv
 
 

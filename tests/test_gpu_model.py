@@ -146,3 +146,30 @@ def test_32_frame_forward_and_loss_vs_golden():
     assert np.abs(got - g["losses"]).max() < 1e-4 * max(1.0, g["losses"][0]), (got, g["losses"])
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_arena_paths_give_the_same_gradients(dtype):
+    """With a ParamArena attached the layers take their fused forms (packed q|k|v projection in the text tower, grouped weight
+    gradients written straight into the arena, deferred bias / LayerNorm reductions): every gradient must equal the one the
+    plain module computes tensor by tensor."""
+    from demovlp_amd import ops
+    F, R, B = 8, 36, 2
+    data = batch(F, R, B)
+    plain = build(F, R, dtype)
+    _, _, _, loss0, _, _ = run(plain, data)
+    loss0.backward()
+    ref = {n: p.grad.detach().float().clone() for n, p in plain.named_parameters() if p.grad is not None}
+    model = build(F, R, dtype)
+    arena = ParamArena(model, bf16_shadow=(dtype == "bfloat16"))
+    FusedAdamW(arena, lr=1e-5)                                      # enables the deferred reductions
+    _, _, _, loss1, _, _ = run(model, data)
+    loss1.backward()
+    ops.flush_reductions()
+    tol = 1e-5 if dtype == "float32" else 4e-2          # bf16: the two paths round differently (one packed GEMM vs three accumulated)
+    assert abs(loss1.item() - loss0.item()) <= tol * max(1.0, abs(loss0.item()))
+    got = {n: p.grad.detach().float() for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref)
+    # (k_lin.bias gradients are mathematically zero -- softmax shift invariance -- so they get an absolute floor)
+    worst = sorted(((max(0.0, float((got[n] - ref[n]).abs().max()) - 1e-7) / max(1e-6, float(ref[n].abs().max())), n) for n in ref if not (dtype == "bfloat16" and n.endswith("k_lin.bias"))), reverse=True)
+    assert worst[0][0] <= tol, worst[:8]
