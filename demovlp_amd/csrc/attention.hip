@@ -36,6 +36,26 @@ struct AttnArgs {
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
+// 8 consecutive channels of a row as floats (one 16-byte read in bf16, two in fp32)
+__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16* p, float (&o)[8]) {
+    const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+__device__ __forceinline__ void store8(float* p, const float (&o)[8]) {
+    *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+__device__ __forceinline__ void store8(bf16* p, const float (&o)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
+    *(bf16x8*)p = v;
+}
+
 template <typename T>
 __device__ __forceinline__ void load_seg_rows(float* dst /*[n][KP]*/, const T* __restrict__ src, int64_t ld, int64_t brow0, int h, int nk,
                                               int incl0, int q0, float mul) {
@@ -94,44 +114,68 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             out[qrow * a.ldo + h * HD + lane] = from_f<T>(o * inv);
         }
     } else {
-        // CLS query (space mode): all N keys, key chunks of 64 dealt round-robin to the 4 waves, online softmax
-        float* red = sm;   // [4][66]: per-wave (m, l, o[64])
-        const float qv = to_f(q[brow0 * a.ld + h * HD + lane]) * a.scale;
-        float m = -INFINITY, l = 0.f, o = 0.f;
-        for (int c0 = wid * 64; c0 < a.N; c0 += 256) {
-            const int key = c0 + lane;
-            float s = -INFINITY;
-            if (key < a.N) {
-                const T* kr = k + (brow0 + key) * a.ld + h * HD;
-                s = 0.f;
-#pragma unroll 8
-                for (int d = 0; d < HD; ++d) s += lane_bcast(qv, d) * to_f(kr[d]);
-                s += a.addmask[brow0 + key];
+        // CLS query (space mode): all N keys.  A wave reads EIGHT key rows per instruction (lane = key 8g + (lane>>3), channels
+        // 8 (lane&7) .. +7, 16 bytes each), so a wave's ~72 keys are ~9 loads that are all in flight at once; a score is an
+        // 8-lane DPP reduction.  (One key per instruction with a wave-wide reduction per key was latency-bound: 40 us.)
+        constexpr int UG = 5;                   // key groups per unrolled step
+        float* S = sm;                          // [N] scores
+        float* red = sm + a.N;                  // [4][64] partial outputs
+        const int kl = lane >> 3, c8 = lane & 7;
+        float q8[8];
+        load8(q + brow0 * a.ld + h * HD + c8 * 8, q8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q8[e] *= a.scale;
+        const int ngroups = (a.N + 7) / 8;
+        for (int g0 = wid; g0 < ngroups; g0 += 4 * UG) {
+            float k8[UG][8];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                int j = 8 * (g0 + 4 * u) + kl;
+                j = j < a.N ? j : a.N - 1;
+                load8(k + (brow0 + j) * a.ld + h * HD + c8 * 8, k8[u]);
             }
-            const float mn = fmaxf(m, wave_max(s));
-            const float alpha = expf(m - mn);
-            const float p = key < a.N ? expf(s - mn) : 0.f;
-            l = l * alpha + wave_sum(p);
-            o *= alpha;
-            const int cnt = a.N - c0 < 64 ? a.N - c0 : 64;
-            for (int j = 0; j < cnt; ++j) o += lane_bcast(p, j) * to_f(v[(brow0 + c0 + j) * a.ld + h * HD + lane]);
-            m = mn;
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int j = 8 * (g0 + 4 * u) + kl;
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += q8[e] * k8[u][e];
+                d = oct_sum(d);
+                if (c8 == 0 && j < a.N) S[j] = d + a.addmask[brow0 + j];
+            }
         }
-        red[wid * 66 + 2 + lane] = o;
-        if (lane == 0) { red[wid * 66] = m; red[wid * 66 + 1] = l; }
         __syncthreads();
-        if (wid == 0) {
-            float M = -INFINITY;
-            for (int w = 0; w < 4; ++w) M = fmaxf(M, red[w * 66]);
-            float L = 0.f, O = 0.f;
-            for (int w = 0; w < 4; ++w) {
-                const float mw = red[w * 66];
-                const float f = mw == -INFINITY ? 0.f : expf(mw - M);
-                L += red[w * 66 + 1] * f;
-                O += red[w * 66 + 2 + lane] * f;
+        float m = -INFINITY;
+        for (int j = lane; j < a.N; j += 64) m = fmaxf(m, S[j]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int j = lane; j < a.N; j += 64) l += expf(S[j] - m);
+        l = wave_sum(l);
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int g0 = wid; g0 < ngroups; g0 += 4 * UG) {
+            float v8[UG][8];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                int j = 8 * (g0 + 4 * u) + kl;
+                j = j < a.N ? j : a.N - 1;
+                load8(v + (brow0 + j) * a.ld + h * HD + c8 * 8, v8[u]);
             }
-            out[brow0 * a.ldo + h * HD + lane] = from_f<T>(O / L);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int j = 8 * (g0 + 4 * u) + kl;
+                const float pj = j < a.N ? expf(S[j] - m) : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] += pj * v8[u][e];
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = stride8_sum(o8[e]);
+        if (kl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wid * 64 + c8 * 8 + e] = o8[e];
+        }
+        __syncthreads();
+        if (wid == 0) out[brow0 * a.ldo + h * HD + lane] = from_f<T>((red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) / l);
     }
 }
 
@@ -236,23 +280,34 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     const int N = a.N;
     const T* q = (const T*)a.q; const T* k = (const T*)a.k; const T* v = (const T*)a.v; const T* dout = (const T*)a.dout;
     T* dq = (T*)a.dq; T* dk = (T*)a.dk; T* dv = (T*)a.dv;
-    float* S = sm; float* DP = S + N; float* red = DP + N;   // red: [4][64] + scalars
-    const float qv = to_f(q[brow0 * a.ld + h * HD + lane]) * a.scale;
-    const float dov = to_f(dout[brow0 * a.ldo + h * HD + lane]);
-    constexpr int CK = 8;
-    // CK keys per wave per step: all loads of a step are issued before the first reduction (the loop is latency-bound)
-    for (int j0 = wid * CK; j0 < N; j0 += 4 * CK) {
-        float kv[CK], vv[CK];
+    float* S = sm; float* DP = S + N; float* red = DP + N;   // red: [4][64]
+    // Eight key rows per load instruction (lane = key 8g + (lane>>3), channels 8 (lane&7) .. +7), a wave's whole share of the
+    // keys in flight at once, scores by 8-lane DPP reductions -- see the forward CLS branch.
+    constexpr int UG = 5;
+    const int kl = lane >> 3, c8 = lane & 7;
+    float q8[8], do8[8];
+    load8(q + brow0 * a.ld + h * HD + c8 * 8, q8);
+    load8(dout + brow0 * a.ldo + h * HD + c8 * 8, do8);
 #pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            const int j = j0 + u < N ? j0 + u : N - 1;
-            kv[u] = to_f(k[(brow0 + j) * a.ld + h * HD + lane]);
-            vv[u] = to_f(v[(brow0 + j) * a.ld + h * HD + lane]);
+    for (int e = 0; e < 8; ++e) q8[e] *= a.scale;
+    const int ngroups = (N + 7) / 8;
+    for (int g0 = wid; g0 < ngroups; g0 += 4 * UG) {
+        float k8[UG][8], v8[UG][8];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            int j = 8 * (g0 + 4 * u) + kl;
+            j = j < N ? j : N - 1;
+            load8(k + (brow0 + j) * a.ld + h * HD + c8 * 8, k8[u]);
+            load8(v + (brow0 + j) * a.ld + h * HD + c8 * 8, v8[u]);
         }
 #pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            const float s = wave_sum(qv * kv[u]), dp = wave_sum(dov * vv[u]);
-            if (lane == 0 && j0 + u < N) { S[j0 + u] = s + a.addmask[brow0 + j0 + u]; DP[j0 + u] = dp; }
+        for (int u = 0; u < UG; ++u) {
+            const int j = 8 * (g0 + 4 * u) + kl;
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc += q8[e] * k8[u][e]; dp += do8[e] * v8[u][e]; }
+            sc = oct_sum(sc); dp = oct_sum(dp);
+            if (c8 == 0 && j < N) { S[j] = sc + a.addmask[brow0 + j]; DP[j] = dp; }
         }
     }
     __syncthreads();
@@ -264,33 +319,48 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(AttnArgs a) {
     for (int j = lane; j < N; j += 64) { const float e = expf(S[j] - m); l += e; pd += e * DP[j]; }
     l = wave_sum(l); pd = wave_sum(pd);
     const float inv = 1.f / l, Dsum = pd * inv;
-    float dqa = 0.f;
-    for (int j0 = wid * CK; j0 < N; j0 += 4 * CK) {
-        float kk[CK], gk0[CK], gv0[CK];
+    float dq8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int g0 = wid; g0 < ngroups; g0 += 4 * UG) {
+        float k8[UG][8], gk[UG][8], gv[UG][8];
 #pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            const int j = j0 + u < N ? j0 + u : N - 1;
-            kk[u] = to_f(k[(brow0 + j) * a.ld + h * HD + lane]);
-            if (j == 0) { gk0[u] = 0.f; gv0[u] = 0.f; }
-            else { gk0[u] = to_f(dk[(brow0 + j) * a.ldd + h * HD + lane]); gv0[u] = to_f(dv[(brow0 + j) * a.ldd + h * HD + lane]); }
+        for (int u = 0; u < UG; ++u) {
+            int j = 8 * (g0 + 4 * u) + kl;
+            j = j < N ? j : N - 1;
+            load8(k + (brow0 + j) * a.ld + h * HD + c8 * 8, k8[u]);
+            if (j == 0) {
+                // the CLS key: totals of the per-frame partials left by launch 1
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gk[u][e] = 0.f; gv[u][e] = 0.f; }
+                const float* w = a.ws + (((int64_t)b * a.H + h) * a.F) * 2 * HD;
+                for (int f = 0; f < a.F; ++f) {
+                    float t0[8], t1[8];
+                    load8(w + f * 2 * HD + c8 * 8, t0); load8(w + f * 2 * HD + HD + c8 * 8, t1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gk[u][e] += t0[e]; gv[u][e] += t1[e]; }
+                }
+            } else {
+                load8(dk + (brow0 + j) * a.ldd + h * HD + c8 * 8, gk[u]);
+                load8(dv + (brow0 + j) * a.ldd + h * HD + c8 * 8, gv[u]);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < CK; ++u) {
-            const int j = j0 + u;
+        for (int u = 0; u < UG; ++u) {
+            const int j = 8 * (g0 + 4 * u) + kl;
             if (j < N) {
-                const float p = expf(S[j] - m) * inv, ds = p * (DP[j] - Dsum);
-                const int64_t offd = (brow0 + j) * a.ldd + h * HD + lane;
-                dqa += ds * kk[u];
-                float gk = ds * qv + gk0[u], gv = p * dov + gv0[u];
-                if (j == 0) {
-                    const float* w = a.ws + (((int64_t)b * a.H + h) * a.F) * 2 * HD;
-                    for (int f = 0; f < a.F; ++f) { gk += w[f * 2 * HD + lane]; gv += w[f * 2 * HD + HD + lane]; }
-                }
-                dk[offd] = from_f<T>(gk); dv[offd] = from_f<T>(gv);
+                const float pj = expf(S[j] - m) * inv, ds = pj * (DP[j] - Dsum);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dq8[e] += ds * k8[u][e]; gk[u][e] += ds * q8[e]; gv[u][e] += pj * do8[e]; }
+                store8(dk + (brow0 + j) * a.ldd + h * HD + c8 * 8, gk[u]);
+                store8(dv + (brow0 + j) * a.ldd + h * HD + c8 * 8, gv[u]);
             }
         }
     }
-    red[wid * 64 + lane] = dqa;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq8[e] = stride8_sum(dq8[e]);
+    if (kl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wid * 64 + c8 * 8 + e] = dq8[e];
+    }
     __syncthreads();
     if (wid == 0) dq[brow0 * a.ldd + h * HD + lane] = from_f<T>((red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) * a.scale);
 }
@@ -819,7 +889,7 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
     if (int rc = attn_check(a)) return rc;
     const int nseg = mode == 0 ? (int)F : 1, nk = (int)R + (mode == 0 ? 1 : 0);
     size_t lds = (size_t)(2 * nk * KP + KMAX) * sizeof(float);
-    if (lds < 4 * 66 * sizeof(float)) lds = 4 * 66 * sizeof(float);
+    if (mode == 0 && lds < (size_t)(N + 256) * sizeof(float)) lds = (size_t)(N + 256) * sizeof(float);     // CLS workgroup: scores [N] + partial outputs
     dim3 grid((unsigned)(nseg + (mode == 0 ? 1 : 0)), (unsigned)H, (unsigned)B), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DVLP_F32) {

@@ -70,6 +70,16 @@ __device__ __forceinline__ float col4_max(float v) {
     auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
+// all-reduce inside each aligned group of 8 lanes (a 64-channel row read as 8 lanes x 8 channels)
+__device__ __forceinline__ float oct_sum(float v) {
+    v += dvlp_dpp<0xB1>(v); v += dvlp_dpp<0x4E>(v); v += dvlp_dpp<0x141>(v);
+    return v;
+}
+// all-reduce over the eight lanes {c, c+8, ..., c+56} that share lane&7: row_ror:8 is the xor-8 step inside a 16-lane row
+__device__ __forceinline__ float stride8_sum(float v) {
+    v += dvlp_dpp<0x128>(v);
+    return col4_sum(v);
+}
 // all-reduce inside each 16-lane row only (the MFMA attention kernels' per-query statistics in the "S" layout)
 __device__ __forceinline__ float row16_sum(float v) {
     v += dvlp_dpp<0xB1>(v); v += dvlp_dpp<0x4E>(v); v += dvlp_dpp<0x141>(v); v += dvlp_dpp<0x140>(v);

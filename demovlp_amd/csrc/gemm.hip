@@ -16,6 +16,7 @@
 //            transposing LDS read (ds_read_b64_tr_b16), so no activation transposes are materialised in HBM.
 #include "common.h"
 #include <vector>
+#include <cstdlib>
 
 struct Epi {
     const float* bias;   // [N] fp32 or null

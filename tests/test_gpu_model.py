@@ -171,5 +171,8 @@ def test_arena_paths_give_the_same_gradients(dtype):
     got = {n: p.grad.detach().float() for n, p in model.named_parameters() if p.grad is not None}
     assert set(got) == set(ref)
     # (k_lin.bias gradients are mathematically zero -- softmax shift invariance -- so they get an absolute floor)
-    worst = sorted(((max(0.0, float((got[n] - ref[n]).abs().max()) - 1e-7) / max(1e-6, float(ref[n].abs().max())), n) for n in ref if not (dtype == "bfloat16" and n.endswith("k_lin.bias"))), reverse=True)
+    if dtype == "float32":
+        worst = sorted(((max(0.0, float((got[n] - ref[n]).abs().max()) - 1e-7) / max(1e-6, float(ref[n].abs().max())), n) for n in ref), reverse=True)
+    else:   # bf16: per-tensor relative L2 error (the max over a sparse gradient such as the word embeddings' is one noisy element)
+        worst = sorted(((float((got[n] - ref[n]).norm()) / max(1e-6, float(ref[n].norm())), n) for n in ref if not n.endswith("k_lin.bias")), reverse=True)
     assert worst[0][0] <= tol, worst[:8]
