@@ -427,6 +427,25 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[NT][2], const bf16* _
     }
 }
 
+// write row fragments (load_row_frags layout) into a row-major LDS tile and zero rows [16 NT, 16 NTP): the tile the
+// transposing reads need is built from registers the wave already holds instead of a second trip to global memory
+// (each extra load -> wait -> use phase costs a wave ~3 us of exposed latency, and these kernels are nothing but such phases)
+template <int NT, int NTP>
+__device__ __forceinline__ void put_row_frags(bf16* Ts, const bf16x8 (&f)[NT][2], int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        *(bf16x8*)&Ts[(16 * t + c) * VLD + 8 * g] = f[t][0];
+        *(bf16x8*)&Ts[(16 * t + c) * VLD + 32 + 8 * g] = f[t][1];
+    }
+    const bf16x8 z = {};
+#pragma unroll
+    for (int t = NT; t < NTP; ++t) {
+        *(bf16x8*)&Ts[(16 * t + c) * VLD + 8 * g] = z;
+        *(bf16x8*)&Ts[(16 * t + c) * VLD + 32 + 8 * g] = z;
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     bf16x8 r;
     r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];
@@ -448,10 +467,9 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
     const int64_t brow0 = (int64_t)b * a.N;
     const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; bf16* out = (bf16*)a.out;
     bf16* Vs = (bf16*)smraw + wid * (NKTP * 16 * VLD);
-    stage_tile<NKTP * 16>(Vs, v, brow0, a.ld, h, sg, true, lane);
-
-    bf16x8 qf[NQT][2];
+    bf16x8 qf[NQT][2], vfr[NKT][2];
     load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
+    load_row_frags<NKT>(vfr, v, brow0, a.ld, h, sg, true, lane);      // one load phase: V goes to LDS from registers below
     f32x4 st[NKT][NQT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -466,6 +484,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
             st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qt][1], acc, 0, 0, 0);
         }
     }
+    put_row_frags<NKT, NKTP>(Vs, vfr, lane);
     float mk[NKT][4];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[kt][qt][r] = st[kt][qt][r] * (dp[kt][qt][r] - D);      // dS^T
         }
-        stage_tile<NKTP * 16>(Ts, k, brow0, a.ld, h, sg, true, lane);
+        put_row_frags<NKT, NKTP>(Ts, kf, lane);
         f32x4 acc[NQT][4];
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt)
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
         // dV[key][d] = sum_q P[q][key] dO[q][d]
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            stage_tile<NQTP * 16>(Ts, pass == 0 ? dout : q, brow0, pass == 0 ? a.ldo : a.ld, h, sg, false, lane);
+            if (pass == 0) put_row_frags<NQT, NQTP>(Ts, gf, lane); else put_row_frags<NQT, NQTP>(Ts, qf, lane);
             f32x4 acc[NKT][4];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the object tower's space attention (forward, backward) at the bench shape.  Usage: python tools/attn_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from demovlp_amd import ops  # noqa: E402
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    B, F, R = 64, 8, 36
+    N = 1 + F * R
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B * N, 2304, device="cuda", generator=g).to(torch.bfloat16)
+    dout = torch.randn(B * N, 768, device="cuda", generator=g).to(torch.bfloat16)
+    mask = torch.zeros(B, N, device="cuda")
+    mb = 2.0 * B * N * 2304 / 1e6
+    t = bench(lambda: ops.space_attention_fwd(qkv, mask, B, F, R))
+    print("space attention fwd  %7.1f us   (qkv read %.0f MB + out %.0f MB -> %.2f TB/s)" % (t, mb, mb / 3, (mb + mb / 3) / t))
+    t = bench(lambda: ops.space_attention_bwd(qkv, mask, dout, B, F, R))
+    print("space attention bwd  %7.1f us   (qkv + dout read, dqkv written: %.0f MB -> %.2f TB/s)" % (t, 2 * mb + mb / 3, (2 * mb + mb / 3) / t))
+
+
+if __name__ == "__main__":
+    main()
