@@ -32,7 +32,10 @@ struct AttnArgs {
     int B, N, H, F, R, mode;
     float scale;
     int seg_begin;             // first segment index served by blockIdx.x = 0 (CLS-only launches start at nseg)
+    int abl;                   // TIMING-ONLY ablation bits (tools/attn_bench.py): 0 in production
 };
+static int g_attn_abl = 0;
+extern "C" int dvlp_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
@@ -446,6 +449,27 @@ __device__ __forceinline__ void put_row_frags(bf16* Ts, const bf16x8 (&f)[NT][2]
     }
 }
 
+// Store NT accumulator tiles (rows 16 t + 4 g + r, channel 16 dt + c per lane: the MFMA C layout) to token rows of a
+// [.., ld] global tensor through the wave's LDS tile, so that global memory sees 16-byte stores of whole 128-byte head rows
+// instead of 2-byte ones.  `keys`: rows are keys (row 0 = the shared CLS key, skipped here) else queries.
+template <int NT>
+__device__ __forceinline__ void emit_rows(bf16* Ts, const f32x4 (&acc)[NT][4], float mul, bf16* __restrict__ dst, int64_t brow0, int64_t ld, int h,
+                                          const Seg& sg, bool keys, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) Ts[(16 * t + 4 * g + r) * VLD + 16 * dt + c] = (bf16)(acc[t][dt][r] * mul);
+#pragma unroll
+    for (int it = 0; it < NT * 2; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const int tok = keys ? (row == 0 ? -1 : sg.tok_k(row)) : sg.tok_q(row);
+        if (tok >= 0) *(uint4*)(dst + (brow0 + tok) * ld + h * HD + ch * 8) = *(const uint4*)&Ts[row * VLD + ch * 8];
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     bf16x8 r;
     r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];
@@ -530,17 +554,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
             for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[qt], vb, o[qt][dt], 0, 0, 0);
         }
     }
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tok = sg.tok_q(16 * qt + 4 * g + r);
-            if (tok >= 0) {
-                bf16* orow = out + (brow0 + tok) * a.ldo + h * HD + c;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)o[qt][dt][r];
-            }
-        }
+    emit_rows<NQT>(Vs, o, 1.f, out, brow0, a.ldo, h, sg, false, lane);
 }
 
 // backward, space mode: one wave per (b, h, frame).  Layout 1 (S^T) -> dQ; layout 2 (S) -> dK, dV.  P is recomputed.
@@ -626,17 +640,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
                 for (int qt = 0; qt < NQT; ++qt) acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qt], kb, acc[qt][dt], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tok = sg.tok_q(16 * qt + 4 * g + r);
-                if (tok >= 0) {
-                    bf16* orow = dq + (brow0 + tok) * a.ldd + h * HD + c;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)(acc[qt][dt][r] * a.scale);
-                }
-            }
+        emit_rows<NQT>(Ts, acc, a.scale, dq, brow0, a.ldd, h, sg, false, lane);
     }
     // ---------------- layout 2: queries on (g, r), keys on lane&15 -> dV, dK ----------------
     if (PART == 1) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
                 m = row16_max(m);
                 float sum = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = expf(s2[qt][kt][r] - m); sum += s2[qt][kt][r]; }
+                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = (a.abl & 2) ? s2[qt][kt][r] - m : expf(s2[qt][kt][r] - m); sum += s2[qt][kt][r]; }
                 sum = row16_sum(sum);
                 const float inv = qok ? 1.f / sum : 0.f;                    // padded query rows contribute nothing
                 float D = 0.f;
@@ -679,6 +683,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) dp[qt][kt][r] = s2[qt][kt][r] * (dp[qt][kt][r] - D);   // dS
             }
+        if (a.abl & 4) { if (dp[0][0][0] == 123.4567f) dk[0] = (bf16)1.f; return; }
         // dV[key][d] = sum_q P[q][key] dO[q][d]
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -708,21 +713,13 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
             }
             const float mul = pass == 0 ? 1.f : a.scale;
             bf16* dst = pass == 0 ? dv : dk;
+            if (a.abl & 1) { if (acc[0][0][0] == 123.4567f) dst[0] = (bf16)1.f; continue; }
+            if (g == 0) {          // key 0 of the frame = the shared CLS key: fp32 partial for the second launch
+                float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + sg.f) * 2 + (pass == 0 ? 1 : 0)) * HD + c;
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * kt + 4 * g + r;
-                    if (j == 0) {
-                        float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + sg.f) * 2 + (pass == 0 ? 1 : 0)) * HD + c;
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[kt][dt][r] * mul;
-                    } else if (j <= a.R) {
-                        bf16* orow = dst + (brow0 + sg.f * a.R + j) * a.ldd + h * HD + c;
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) orow[16 * dt] = (bf16)(acc[kt][dt][r] * mul);
-                    }
-                }
+                for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[0][dt][0] * mul;
+            }
+            emit_rows<NKT>(Ts, acc, mul, dst, brow0, a.ldd, h, sg, true, lane);
         }
     }
 }
@@ -903,6 +900,7 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
                                   const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, void* stream) {
     dvlp_clear_status();
     AttnArgs a{};
+    a.abl = g_attn_abl;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.out = out; a.ldo = ldo;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
     if (int rc = attn_check(a)) return rc;
@@ -951,6 +949,7 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
                                   void* dv, int64_t ldd, float* workspace, float scale, void* stream) {
     dvlp_clear_status();
     AttnArgs a{};
+    a.abl = g_attn_abl;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.dout = dout; a.ldo = ldo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd;
     a.ws = workspace;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;

@@ -81,6 +81,16 @@ template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&o)
 template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o)[4]) { float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 template <> __device__ __forceinline__ void ld4<bf16>(const bf16* p, float (&o)[4]) { bf16x4 v = *(const bf16x4*)p; o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float (&o)[8]) {
+    const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4]) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
 template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&o)[4]) { bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3]; *(bf16x4*)p = v; }
 
@@ -131,12 +141,43 @@ template <typename T>
 __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, float* Ssm, float* rn, float* cn, float* cpart /*[8][W]*/) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const T* S = (const T*)a.S;
-    for (int g = wid; g < a.G; g += nw) {
-        const T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
-        float q = 0.f;
-        for (int w = lane; w < a.W; w += 64) { const float v = to_f(row[w]); Ssm[g * a.Wq + w] = v; q += v * v; }
-        q = wave_sum(q);
-        if (lane == 0) rn[g] = 1.f / (sqrtf(q) + 1e-8f);
+    const int CH = a.Wp >> 3;                       // 16-byte (bf16) chunks per row; Wp is a multiple of 8
+    if (CH <= 16) {
+        // Four rows per wave-instruction (16 lanes x 8 elements each) and a wave's whole share of the tile in flight at once:
+        // one workgroup per CU owns this tile, so a row-at-a-time loop (load -> reduce -> next row) was 18 dependent memory
+        // round trips per wave -- a third of the kernel.
+        constexpr int UR = 5;
+        const int sub = lane & 15, slot = lane >> 4;
+        for (int q0 = wid; 4 * q0 < a.G; q0 += nw * UR) {
+            float v[UR][8];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int g = 4 * (q0 + nw * u) + slot;
+                const bool ok = g < a.G && sub < CH;
+                ld8<T>(S + (((int64_t)i * a.G + (ok ? g : 0)) * a.Bj + j) * a.Wp + (ok ? sub : 0) * 8, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int g = 4 * (q0 + nw * u) + slot;
+                const bool ok = g < a.G && sub < CH;
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int w = sub * 8 + e;
+                    if (ok && w < a.W) { Ssm[g * a.Wq + w] = v[u][e]; q += v[u][e] * v[u][e]; }
+                }
+                q = row16_sum(q);
+                if (sub == 0 && g < a.G) rn[g] = 1.f / (sqrtf(q) + 1e-8f);
+            }
+        }
+    } else {
+        for (int g = wid; g < a.G; g += nw) {
+            const T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
+            float q = 0.f;
+            for (int w = lane; w < a.W; w += 64) { const float v = to_f(row[w]); Ssm[g * a.Wq + w] = v; q += v * v; }
+            q = wave_sum(q);
+            if (lane == 0) rn[g] = 1.f / (sqrtf(q) + 1e-8f);
+        }
     }
     __syncthreads();
     {

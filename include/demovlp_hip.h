@@ -66,6 +66,8 @@ int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes);
 int dvlp_prof_enable(int on);
 int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 
+/* TIMING-ONLY ablation of the MFMA attention backward (1 no stores, 2 no exp, 4 stop after the softmax); 0 in production */
+int dvlp_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */
 int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,
                        void* y_relu, float* mean, float* rstd, void* stream);

@@ -23,6 +23,8 @@ def bench(fn, iters=20):
 
 
 def main():
+    if len(sys.argv) > 1:
+        ops.call("dvlp_attention_ablate", int(sys.argv[1]))
     B, F, R = 64, 8, 36
     N = 1 + F * R
     g = torch.Generator(device="cuda").manual_seed(0)
