@@ -176,3 +176,84 @@ def test_arena_paths_give_the_same_gradients(dtype):
     else:   # bf16: per-tensor relative L2 error (the max over a sparse gradient such as the word embeddings' is one noisy element)
         worst = sorted(((float((got[n] - ref[n]).norm()) / max(1e-6, float(ref[n].norm())), n) for n in ref if not n.endswith("k_lin.bias")), reverse=True)
     assert worst[0][0] <= tol, worst[:8]
+
+
+def _dp2_worker(rank, world, port, q):
+    """One data-parallel rank (both ranks share cuda:0; gloo carries the gradient buckets) running the real HIP step."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        F, R, B = 8, 36, 2
+        model = build(F, R)
+        arena = ParamArena(model)
+        opt = FusedAdamW(arena, lr=1e-3)
+        reducer = GradReducer(arena, bucket_mb=64.0)
+        loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+        data = _dp2_batch(F, R, B, rank)
+        losses = []
+        for _ in range(2):
+            l, _, _ = train_step(model, loss_fn, opt, data, reducer)
+            losses.append(float(l.item()))
+        torch.cuda.synchronize()
+        q.put((rank, losses, arena.flat_p[::9973].double().cpu().numpy(), len(reducer.buckets), sorted(reducer.tail)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp2_batch(F, R, B, rank):
+    obj, mask = syn.fast_region_batch(B, F, R, seed=11 + rank)
+    ids, att = syn.caption_batch(B, first_sample=rank * B)
+    return {"text": {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(att).to(DEV)},
+            "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
+
+
+def test_two_rank_data_parallel_step_matches_averaged_gradients():
+    """The multi-GPU path on one GPU: two processes, each its own batch, GradReducer all-reducing arena buckets from the
+    post-accumulate hooks (tail bucket after the deferred flush), 1/world folded into fused AdamW.  Both ranks must end
+    with the same parameters, equal to a single process that averages the two batches' gradients itself."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+    (_, l0, p0, nb, tail), (_, l1, p1, _, _) = res
+    assert nb >= 3 and tail == [nb - 1]                       # several weight buckets + the vector tail
+    assert np.array_equal(p0, p1)                              # ranks stay in lock step, bit for bit
+    # single-process reference: average the two ranks' gradients by hand
+    from demovlp_amd import ops
+    F, R, B = 8, 36, 2
+    model = build(F, R)
+    arena = ParamArena(model)
+    opt = FusedAdamW(arena, lr=1e-3)
+    loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+    ref_losses = []
+    for _ in range(2):
+        acc, ls = torch.zeros_like(arena.flat_g), []
+        for rank in range(2):
+            opt.zero_grad()
+            data = _dp2_batch(F, R, B, rank)
+            out = model(data)
+            tmask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+            tlen = data["text"]["attention_mask"].sum(1)
+            gsim = sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"])
+            loss, _, _ = loss_fn(gsim, out["local_object_embeddings"], out["local_text_embeddings"], out["object_mask"], tlen, tmask)
+            loss.backward()
+            ops.flush_reductions()
+            arena.zero_untouched(lambda i: arena.params[i].grad is not None)
+            acc += arena.flat_g
+            ls.append(float(loss.item()))
+        ref_losses.append(ls)
+        arena.flat_g.copy_(acc)
+        opt.step(grad_scale=0.5)
+    for step in range(2):
+        assert abs(l0[step] - ref_losses[step][0]) < 1e-5 * max(1.0, abs(l0[step])) and abs(l1[step] - ref_losses[step][1]) < 1e-5 * max(1.0, abs(l1[step]))
+    pref = arena.flat_p[::9973].double().cpu().numpy()
+    assert np.abs(p0 - pref).max() <= 1e-5 * max(1.0, np.abs(pref).max())
