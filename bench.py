@@ -111,7 +111,8 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("DVLP_FORCE_DIST") is not None and "MASTER_ADDR" in os.environ   # developer switch:
+    if world > 1 or force_dist:                                                                              # RCCL path on one GPU
         dist.init_process_group("nccl", device_id=dev)
 
     from demovlp_amd import ops, synthetic as syn
@@ -131,7 +132,7 @@ def main():
         ops.call("dvlp_gemm_p8_mode", a.p8)
     arena = ParamArena(model, bf16_shadow=(a.dtype == "bf16"))
     opt = FusedAdamW(arena, lr=1e-5)
-    reducer = GradReducer(arena, bucket_mb=64.0) if world > 1 else None
+    reducer = GradReducer(arena, bucket_mb=64.0, always_reduce=force_dist) if (world > 1 or force_dist) else None
     loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
 
     obj, mask = syn.fast_region_batch(B, F, R, seed=7 + rank)
@@ -140,7 +141,7 @@ def main():
             "object": torch.from_numpy(obj).to(dev), "object_mask": torch.from_numpy(mask).to(dev)}
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,7 +206,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, R)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

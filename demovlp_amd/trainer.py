@@ -139,10 +139,12 @@ class GradReducer:
     collective.  A bucket is launched (async, on the communication stream) as soon as every parameter in it that is
     known to receive a gradient has fired its post-accumulate hook; ``finish()`` launches the rest and waits."""
 
-    def __init__(self, arena: ParamArena, bucket_mb: float = 64.0, group=None):
+    def __init__(self, arena: ParamArena, bucket_mb: float = 64.0, group=None, always_reduce: bool = False):
         self.arena = arena
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # always_reduce: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
+        self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []          # (lo, hi, [param indices])
         lo, idxs = 0, []
@@ -174,7 +176,7 @@ class GradReducer:
     def _make_hook(self, i):
         def hook(_p):
             self._seen.add(i)
-            if self.expected is None or self.world == 1:
+            if self.expected is None or not self.collective:
                 return
             b = self.bucket_of[i]
             self._pending[b].discard(i)
@@ -209,7 +211,7 @@ class GradReducer:
         if a.flat_g.is_cuda:
             ops.flush_reductions()         # finishes the vector gradients of the tail bucket(s)
         a.zero_untouched(lambda i: i in self._seen)
-        if self.world > 1:
+        if self.collective:
             for b in range(len(self.buckets)):
                 if b not in self._launched:
                     self._launch(b)
