@@ -35,6 +35,8 @@ struct AttnArgs {
     int abl;                   // TIMING-ONLY ablation bits (tools/attn_bench.py): 0 in production
 };
 static int g_attn_abl = 0;
+static int g_attn_merged = 1;      // space-mode bf16 backward: 1 = one-pass form, 0 = the three-launch form (A/B, tests)
+extern "C" int dvlp_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
 extern "C" int dvlp_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
@@ -385,8 +387,9 @@ constexpr int VLD = 72;    // LDS tile row stride in elements (144 B: 16-byte al
 
 struct Seg {
     int mode, R, L, f, qbase;
+    int cls_q = 0;             // space mode: query row R of the tile is the CLS token (merged backward)
     __device__ __forceinline__ int tok_q(int i) const {
-        if (mode == 0) return i < R ? 1 + f * R + i : -1;
+        if (mode == 0) return i < R ? 1 + f * R + i : (cls_q && i == R ? 0 : -1);
         const int t = qbase + i;
         return t < L ? t : -1;
     }
@@ -725,6 +728,239 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// Space-mode backward in ONE pass over q, k, v, dO (bf16).  The three-launch form above reads them twice in the two frame
+// launches and then read-modify-writes every dK / dV row in the CLS launch: ~625 MB per layer for 200 MB of useful traffic,
+// and the kernels are HBM-bound.  Here:
+//   launch A (attn_bwd_cls_pre_kernel, one workgroup per (b, h)): the CLS query's softmax statistics over all N keys
+//            (max, sum, D = sum_j p_j <dO_cls, v_j>) -> stats[b][h][0..2], and dq_cls;
+//   launch B (this kernel, one wave per (b, h, frame)): layout 2 only.  The CLS query rides along as query row R of every
+//            frame tile, normalised with the GLOBAL statistics of launch A instead of the tile's own, so its contributions
+//            to dK / dV of the frame's keys come out of the same MFMAs (its product with the CLS key is kept in frame 0
+//            only).  dQ = dS K goes through the wave's LDS tile: dS (C layout) is written as bf16 and read back as the A
+//            operand, K is read with the transposing read.  Per-frame partials of the shared CLS key go to `ws` as before;
+//   launch C (attn_bwd_cls_post_kernel): sums those partials into dK / dV of the CLS key.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void mattn_bwd_space_merged_kernel(AttnArgs a, int items, const float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int NTP = (NT + 1) & ~1, TROWS = 16 * NTP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int item = blockIdx.x * 4 + wid;
+    if (item >= items) return;
+    Seg sg{0, a.R, a.N, item % a.F, 0, 1};                  // queries: the frame's R regions + the CLS query as row R
+    Seg sgp{0, a.R, a.N, item % a.F, 0, 0};                 // the same without the CLS row (dQ rows written here)
+    const int h = (item / a.F) % a.H, b = item / (a.F * a.H);
+    const int64_t brow0 = (int64_t)b * a.N;
+    const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; const bf16* dout = (const bf16*)a.dout;
+    bf16* dq = (bf16*)a.dq; bf16* dk = (bf16*)a.dk; bf16* dv = (bf16*)a.dv;
+    bf16* Ts = (bf16*)smraw + wid * (TROWS * VLD);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* st3 = stats + ((int64_t)b * a.H + h) * 4;
+    const float m_cls = st3[0], il_cls = 1.f / st3[1], D_cls = st3[2];
+
+    bf16x8 qf[NT][2], gf[NT][2], kf[NT][2], vf[NT][2];
+    load_row_frags<NT>(qf, q, brow0, a.ld, h, sg, false, lane);
+    load_row_frags<NT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
+    load_row_frags<NT>(kf, k, brow0, a.ld, h, sg, true, lane);
+    load_row_frags<NT>(vf, v, brow0, a.ld, h, sg, true, lane);
+    f32x4 s2[NT][NT], dp[NT][NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][0], kf[kt][0], zero4, 0, 0, 0);
+            s2[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][1], kf[kt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][0], vf[kt][0], zero4, 0, 0, 0);
+            dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][1], vf[kt][1], acc, 0, 0, 0);
+        }
+    float mk[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) { const int tok = sg.tok_k(16 * kt + c); mk[kt] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = 16 * qt + 4 * g + r;
+            const bool qok = sg.tok_q(qi) >= 0, is_cls = qi == a.R;
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) { s2[qt][kt][r] = s2[qt][kt][r] * a.scale + mk[kt]; m = fmaxf(m, s2[qt][kt][r]); }
+            m = row16_max(m);
+            if (is_cls) m = m_cls;                                       // the CLS query's softmax spans all N keys
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                float e = expf(s2[qt][kt][r] - m);
+                if (is_cls && kt == 0 && c == 0 && sg.f != 0) e = 0.f;    // CLS query x CLS key: counted once, in frame 0
+                s2[qt][kt][r] = e; sum += e;
+            }
+            sum = row16_sum(sum);
+            const float inv = is_cls ? il_cls : (qok ? 1.f / sum : 0.f);      // padded query rows contribute nothing
+            float D = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) { s2[qt][kt][r] *= inv; D += s2[qt][kt][r] * dp[qt][kt][r]; }
+            D = row16_sum(D);
+            if (is_cls) D = D_cls;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) dp[qt][kt][r] = s2[qt][kt][r] * (dp[qt][kt][r] - D);   // dS
+        }
+    // dV[key][d] = sum_q P[q][key] dO[q][d];  dK[key][d] = scale * sum_q dS[q][key] Q[q][d]
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0) put_row_frags<NT, NTP>(Ts, gf, lane); else put_row_frags<NT, NTP>(Ts, qf, lane);
+        f32x4 acc[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[kt][dt] = zero4;
+#pragma unroll
+        for (int s = 0; s < NTP / 2; ++s) {
+            const int qt0 = 2 * s, qt1 = 2 * s + 1;
+            bf16x8 pa[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const f32x4& lo = pass == 0 ? s2[qt0][kt] : dp[qt0][kt];
+                const f32x4& hi = qt1 < NT ? (pass == 0 ? s2[qt1 < NT ? qt1 : qt0][kt] : dp[qt1 < NT ? qt1 : qt0][kt]) : zero4;
+                pa[kt] = pack8(lo, hi);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 xb = tr_pair(lds_addr(&Ts[(16 * qt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                          lds_addr(&Ts[(16 * qt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[kt], xb, acc[kt][dt], 0, 0, 0);
+            }
+        }
+        const float mul = pass == 0 ? 1.f : a.scale;
+        bf16* dst = pass == 0 ? dv : dk;
+        if (g == 0) {          // key 0 of the frame = the shared CLS key: fp32 partial for launch C
+            float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + sg.f) * 2 + (pass == 0 ? 1 : 0)) * HD + c;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[0][dt][0] * mul;
+        }
+        emit_rows<NT>(Ts, acc, mul, dst, brow0, a.ldd, h, sg, true, lane);
+    }
+    // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: K through the tile (transposing read, natural key order), then dS
+    put_row_frags<NT, NTP>(Ts, kf, lane);
+    bf16x8 kb[NTP / 2][4];
+#pragma unroll
+    for (int ks = 0; ks < NTP / 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            kb[ks][dt] = tr_pair(lds_addr(&Ts[(32 * ks + 8 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                 lds_addr(&Ts[(32 * ks + 8 * g + 4 + qq) * VLD + 16 * dt + 4 * pp]));
+    // (columns >= 16 NT of the rows written next keep finite K values; they meet the zero K rows of the padded k-step)
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ts[(16 * qt + 4 * g + r) * VLD + 16 * kt + c] = (bf16)dp[qt][kt][r];
+    f32x4 dqa[NT][4];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = zero4;
+#pragma unroll
+    for (int ks = 0; ks < NTP / 2; ++ks)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            const bf16x8 dsf = *(const bf16x8*)&Ts[(16 * qt + c) * VLD + 32 * ks + 8 * g];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, kb[ks][dt], dqa[qt][dt], 0, 0, 0);
+        }
+    emit_rows<NT>(Ts, dqa, a.scale, dq, brow0, a.ldd, h, sgp, false, lane);
+}
+
+// launch A of the merged backward: CLS-query statistics and dq_cls.  stats[b][h] = (max, sum, D, -)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_cls_pre_kernel(AttnArgs a, float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int64_t brow0 = (int64_t)b * a.N;
+    const int N = a.N;
+    const T* q = (const T*)a.q; const T* k = (const T*)a.k; const T* v = (const T*)a.v; const T* dout = (const T*)a.dout;
+    T* dq = (T*)a.dq;
+    float* S = sm; float* DP = S + N; float* red = DP + N;
+    constexpr int UG = 5;
+    const int kl = lane >> 3, c8 = lane & 7;
+    float q8[8], do8[8];
+    load8(q + brow0 * a.ld + h * HD + c8 * 8, q8);
+    load8(dout + brow0 * a.ldo + h * HD + c8 * 8, do8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q8[e] *= a.scale;
+    const int ngroups = (N + 7) / 8;
+    for (int g0 = wid; g0 < ngroups; g0 += 4 * UG) {
+        float k8[UG][8], v8[UG][8];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            int j = 8 * (g0 + 4 * u) + kl;
+            j = j < N ? j : N - 1;
+            load8(k + (brow0 + j) * a.ld + h * HD + c8 * 8, k8[u]);
+            load8(v + (brow0 + j) * a.ld + h * HD + c8 * 8, v8[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int j = 8 * (g0 + 4 * u) + kl;
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc += q8[e] * k8[u][e]; dp += do8[e] * v8[u][e]; }
+            sc = oct_sum(sc); dp = oct_sum(dp);
+            if (c8 == 0 && j < N) { S[j] = sc + a.addmask[brow0 + j]; DP[j] = dp; }
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, S[j]);
+    m = wave_max(m);
+    float l = 0.f, pd = 0.f;
+    for (int j = lane; j < N; j += 64) { const float e = expf(S[j] - m); l += e; pd += e * DP[j]; }
+    l = wave_sum(l); pd = wave_sum(pd);
+    const float inv = 1.f / l, Dsum = pd * inv;
+    if (threadIdx.x == 0) { float* s3 = stats + ((int64_t)b * a.H + h) * 4; s3[0] = m; s3[1] = l; s3[2] = Dsum; s3[3] = 0.f; }
+    float dq8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int g0 = wid; g0 < ngroups; g0 += 4 * UG) {
+        float k8[UG][8];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            int j = 8 * (g0 + 4 * u) + kl;
+            j = j < N ? j : N - 1;
+            load8(k + (brow0 + j) * a.ld + h * HD + c8 * 8, k8[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int j = 8 * (g0 + 4 * u) + kl;
+            if (j < N) {
+                const float ds = expf(S[j] - m) * inv * (DP[j] - Dsum);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dq8[e] += ds * k8[u][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq8[e] = stride8_sum(dq8[e]);
+    if (kl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wid * 64 + c8 * 8 + e] = dq8[e];
+    }
+    __syncthreads();
+    if (wid == 0) dq[brow0 * a.ldd + h * HD + lane] = from_f<T>((red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) * a.scale);
+}
+
+// launch C of the merged backward: dK / dV of the shared CLS key = sum of the per-frame partials
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_cls_post_kernel(AttnArgs a) {
+    const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+    const float* w = a.ws + (((int64_t)b * a.H + h) * a.F) * 2 * HD;
+    float gk = 0.f, gv = 0.f;
+    for (int f = 0; f < a.F; ++f) { gk += w[f * 2 * HD + lane]; gv += w[f * 2 * HD + HD + lane]; }
+    const int64_t off = (int64_t)b * a.N * a.ldd + h * HD + lane;
+    ((T*)a.dk)[off] = from_f<T>(gk);
+    ((T*)a.dv)[off] = from_f<T>(gv);
+}
+
 // backward, full (text) mode: one workgroup per (b, h); K, Q and dO tiles are staged once in LDS and shared; wave w owns
 // query tiles {2w, 2w+1} for dQ (layout 1) and key tiles {2w, 2w+1} for dK / dV (layout 2).  NT = ceil(L / 16) <= 8.
 template <int NT>
@@ -970,6 +1206,18 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
     } else if (dtype == DVLP_BF16) {
         static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void*)attn_bwd_seg_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         bool done = false;
+        // one-pass form (CLS query rides along in the frame tiles): needs R + 1 query rows in <= 3 tiles
+        if (mode == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0 && R + 1 <= 48 && g_attn_merged) {
+            const int nt = (int)cdiv(R + 1, 16), items = (int)(B * H * F);
+            float* stats = workspace + B * H * F * 2 * HD;
+            hipLaunchKernelGGL(attn_bwd_cls_pre_kernel<bf16>, grid2, block, lds2, st, a, stats);
+#define MMRG(NT_) hipLaunchKernelGGL((mattn_bwd_space_merged_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, \
+                                     (size_t)4 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16), st, a, items, (const float*)stats)
+            if (nt == 3) MMRG(3); else if (nt == 2) MMRG(2); else MMRG(1);
+#undef MMRG
+            hipLaunchKernelGGL(attn_bwd_cls_post_kernel<bf16>, grid2, dim3(64), 0, st, a);
+            return dvlp_launch_status();
+        }
         if (mode == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0) {
             const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
             const int items = (int)(B * H * F);

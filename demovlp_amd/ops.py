@@ -272,7 +272,7 @@ def space_attention_bwd(qkv, addmask, dout, B, F, R):
     dqkv = torch.empty_like(qkv)
     es = qkv.element_size()
     b, db = qkv.data_ptr(), dqkv.data_ptr()
-    ws = _workspace("attn", B * HEADS * F * 2 * 64, qkv.device)
+    ws = _workspace("attn", B * HEADS * (F * 2 * 64 + 4), qkv.device)
     call("dvlp_attention_bwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(b), ctypes.c_void_p(b + 768 * es),
          ctypes.c_void_p(b + 1536 * es), 2304, p(addmask), p(dout), 768, ctypes.c_void_p(db), ctypes.c_void_p(db + 768 * es),
          ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, stream())

@@ -66,6 +66,9 @@ int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes);
 int dvlp_prof_enable(int on);
 int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 
+/* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the
+   three-launch form -- for A/B measurements and tests.  Workspace of dvlp_attention_bwd (mode 0): B*H*(F*128 + 4) floats. */
+int dvlp_attention_bwd_variant(int merged);
 /* TIMING-ONLY ablation of the MFMA attention backward (1 no stores, 2 no exp, 4 stop after the softmax); 0 in production */
 int dvlp_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */

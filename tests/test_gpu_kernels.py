@@ -137,9 +137,17 @@ def test_colsum(dtype):
     assert rel(got, t.float().reshape(B, F, R, 768).sum((0, 2))) < tol(dtype)
 
 
+@pytest.fixture(params=[1, 0], ids=["bwd-one-pass", "bwd-three-launch"])
+def attn_bwd_variant(request):
+    """bf16 space-attention backward: the one-pass form (CLS query folded into the frame tiles) and the three-launch form."""
+    ops.call("dvlp_attention_bwd_variant", request.param)
+    yield request.param
+    ops.call("dvlp_attention_bwd_variant", 1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,F,R", [(2, 8, 36), (3, 1, 30), (1, 32, 36), (2, 8, 30)])
-def test_space_attention(dtype, B, F, R):
+@pytest.mark.parametrize("B,F,R", [(2, 8, 36), (3, 1, 30), (1, 32, 36), (2, 8, 30), (2, 4, 15), (2, 3, 47), (1, 2, 50)])
+def test_space_attention(dtype, B, F, R, attn_bwd_variant):
     N = 1 + F * R
     qkv = rnd(B * N, 2304, dtype=dtype, scale=1.5)
     mask01 = (torch.rand(B, N - 1, generator=torch.Generator().manual_seed(1)) > 0.2).float()
