@@ -23,6 +23,7 @@ struct LossArgs {
     int B;
     float temperature, lam;
     int use_global, use_local, stages;   // stages: 1 = sim forward, 2 = losses + dsim/dxs, 4 = embedding grads from dsim
+    int staged;              // both embedding matrices fit in LDS (B <= 64): rows are read from there
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -38,16 +39,24 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 template <typename T>
 __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int B = a.B, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float* nt = sm; float* no = nt + B; float* lse_r = no + B; float* lse_c = lse_r + B; float* red = lse_c + B;
+    float* E = red + 32;                      // staged: [2B][256] fp32 copies of gt (rows 0..B-1) and go (rows B..2B-1)
     const T* gt = (const T*)a.gt; const T* go = (const T*)a.go;
+    // row r of the stacked (gt | go) matrix, 4 channels per lane: from LDS when staged -- this is a ONE-workgroup kernel, so
+    // every row re-read from global memory inside the B x B loops below was a full, unhidden memory round trip
+    auto ldrow = [&](int r, float (&v)[4]) {
+        if (a.staged) { const float4 t = *(const float4*)&E[r * LD_ + lane * 4]; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else l4<T>((r < B ? gt + (int64_t)r * LD_ : go + (int64_t)(r - B) * LD_) + lane * 4, v);
+    };
     float gl = 0.f, ll = 0.f;
     if (a.use_global && (a.stages & 5)) {
         // norms, clamped as in sim_matrix: a / max(|a|, 1e-8)
         for (int r = wid; r < 2 * B; r += nw) {
             float v[4];
             l4<T>((r < B ? gt + (int64_t)r * LD_ : go + (int64_t)(r - B) * LD_) + lane * 4, v);
+            if (a.staged) *(float4*)&E[r * LD_ + lane * 4] = make_float4(v[0], v[1], v[2], v[3]);
             const float n = sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
             if (lane == 0) (r < B ? nt[r] : no[r - B]) = fmaxf(n, 1e-8f);
         }
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
         for (int e = wid; e < B * B; e += nw) {
             const int t = e / B, o = e % B;
             float x[4], y[4];
-            l4<T>(gt + (int64_t)t * LD_ + lane * 4, x); l4<T>(go + (int64_t)o * LD_ + lane * 4, y);
+            ldrow(t, x); ldrow(B + o, y);
             float d = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) d += (x[c] / nt[t]) * (y[c] / no[o]);
@@ -95,19 +104,17 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
         // d/d normalised rows, then through a / max(|a|, eps)
         for (int r = wid; r < 2 * B; r += nw) {
             const bool row = r < B; const int idx = row ? r : r - B;
-            const T* self = (row ? gt : go) + (int64_t)idx * LD_ + lane * 4;
-            const T* other = row ? go : gt;
             const float* on = row ? no : nt;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < B; ++k) {
                 const float w = (row ? a.dsim[idx * B + k] : a.dsim[k * B + idx]) / on[k];
                 float y[4];
-                l4<T>(other + (int64_t)k * LD_ + lane * 4, y);
+                ldrow(row ? B + k : k, y);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] += w * y[c];
             }
             float x[4];
-            l4<T>(self, x);
+            ldrow(r, x);
             const float n = row ? nt[idx] : no[idx];
             float o4[4];
             if (n > 1e-8f) {
@@ -156,9 +163,13 @@ extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const voi
     dvlp_clear_status();
     if (d != LD_ || B <= 0 || B > 2048) return DVLP_ERR_SHAPE;
     if (use_local && !xs) return DVLP_ERR_SHAPE;
-    LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages};
-    const size_t lds = (size_t)(4 * B + 32) * sizeof(float);
+    const int staged = B <= 64 ? 1 : 0;
+    LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages, staged};
+    const size_t lds = (size_t)(4 * B + 32 + (staged ? 2 * B * LD_ : 0)) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    { static bool once = false; if (!once) { once = true;
+        (void)hipFuncSetAttribute((const void*)loss_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)loss_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } }
     if (dtype == DVLP_F32) hipLaunchKernelGGL(loss_kernel<float>, dim3(1), dim3(1024), lds, st, a);
     else if (dtype == DVLP_BF16) hipLaunchKernelGGL(loss_kernel<bf16>, dim3(1), dim3(1024), lds, st, a);
     else return DVLP_ERR_DTYPE;

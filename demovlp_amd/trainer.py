@@ -236,6 +236,7 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
                                             out["object_mask"], text_length, text_mask)
     loss.backward()
     if loss.is_cuda:
+        Fn.join_side_stream()          # deferred partial sums may have been produced on the side stream
         ops.flush_reductions()
     scale = reducer.finish() if reducer is not None else 1.0
     if isinstance(optimizer, FusedAdamW):
