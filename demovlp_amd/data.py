@@ -1,0 +1,120 @@
+"""Region-feature input side of the hot path: what sits between the bottom-up-attention
+`.npz` files and ``ObjectRelation.forward``.
+
+Reference behaviour mirrored here (file:line are into the reference repo):
+  * frame choice per video          base/base_dataset.py:82-101 (`_sample_objects`: 'rand' for training, 'uniform' otherwise)
+  * per-frame `.npz` schema         data_loader/WebVid_dataset.py:243-256 (`x`, `bbox`, `info{objects_conf, objects_id, image_w, image_h}`)
+  * top-R selection / padding / box geometry / mask
+                                    data_loader/WebVid_dataset.py:134-283 -- done ON THE DEVICE by `dvlp_region_select`
+                                    (bit-exact indices, tests/golden/g1_region_select.npz) instead of in DataLoader workers
+  * per-rank sharding               base/base_data_loader.py:23-28 (`DistributedSampler(shuffle, drop_last=True)`, `set_epoch`)
+  * alternating multi-loader epoch  trainer/trainer_dist.py:123-129 (`zip(*loaders)`, one batch of each in turn)
+
+Host work is limited to reading files into pinned staging buffers; the 2.37 MB/sample of fp32 features cross PCIe once,
+raw, and are selected / padded / concatenated to `[B, F, R, 2054]` in HBM.  Dataset metadata (csv/json), tokenisation and
+the torch DataLoader worker pool stay the reference's Python and are out of scope.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+FEAT_DIM = 2048
+
+
+def sample_frame_indices(num_segments: int, num_files: int, mode: str = "rand", rng: Optional[random.Random] = None) -> List[int]:
+    """Frame files to read for one video (base/base_dataset.py:82-101 + WebVid_dataset.py:96-110).  'rand': one random frame per
+    equal interval, sorted; 'uniform': the interval midpoints.  All files in order when there are exactly `num_segments`."""
+    if num_segments == num_files:
+        return list(range(num_segments))
+    acc = min(num_segments, num_files)
+    intervals = np.linspace(start=0, stop=num_files, num=acc + 1).astype(int)
+    ranges = [(int(a), int(b) - 1) for a, b in zip(intervals[:-1], intervals[1:])]
+    if mode == "rand":
+        rng = rng or random
+        return sorted(rng.choice(range(lo, hi)) for lo, hi in ranges)       # `range(lo, hi)`: the reference never picks `hi`
+    if mode == "uniform":
+        return [(lo + hi) // 2 for lo, hi in ranges]
+    raise NotImplementedError(mode)
+
+
+def read_frame_npz(path: str):
+    """One frame file -> (x [N,2048] f32, bbox [N,4] f32, conf [N] f32, (image_w, image_h))."""
+    with np.load(path, allow_pickle=True) as z:
+        info = z["info"].item()
+        return (np.ascontiguousarray(z["x"], np.float32), np.ascontiguousarray(z["bbox"], np.float32),
+                np.ascontiguousarray(info["objects_conf"], np.float32), (float(info["image_w"]), float(info["image_h"])))
+
+
+def shard_indices(n: int, world: int, rank: int, epoch: int = 0, shuffle: bool = True, seed: int = 0) -> np.ndarray:
+    """The index list `DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, drop_last=True)` yields after
+    `set_epoch(epoch)` (base/base_data_loader.py:23-28; torch/utils/data/distributed.py) -- same permutation, same tail drop."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).numpy()
+    else:
+        idx = np.arange(n)
+    per_rank = (n - world + world - 1) // world if n % world != 0 else n // world      # ceil((n - world) / world) when ragged
+    per_rank = max(per_rank, 0)
+    total = per_rank * world
+    return idx[:total][rank:total:world]
+
+
+def alternate(loaders: Sequence[Iterable]) -> Iterator[Tuple[int, object]]:
+    """(loader index, batch) in the order the reference trainer consumes its loaders: one batch of each per round, stopping
+    with the shortest (trainer/trainer_dist.py:123-129)."""
+    for batches in zip(*loaders):
+        for i, b in enumerate(batches):
+            yield i, b
+
+
+class RegionBatcher:
+    """Raw frames of a batch -> `object [B,F,R,2054]` fp32 + `object_mask [B,F,R]` on the device.
+
+    Frames may have different region counts (20-100 in the released features): they are packed into pinned host buffers of
+    `max_regions` rows with a per-frame valid count, copied asynchronously on `copy_stream`, and selected on the device."""
+
+    def __init__(self, batch: int, frames: int, regions: int, max_regions: int = 100, device: str | torch.device = "cuda"):
+        self.B, self.F, self.R, self.M = batch, frames, regions, max_regions
+        self.device = torch.device(device)
+        pin = self.device.type == "cuda"
+        mk = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt).pin_memory() if pin else torch.zeros(*s, dtype=dt)  # noqa: E731
+        self.h_feat, self.h_box = mk(batch, frames, max_regions, FEAT_DIM), mk(batch, frames, max_regions, 4)
+        self.h_conf, self.h_wh = mk(batch, frames, max_regions), mk(batch, frames, 2)
+        self.h_n = mk(batch, frames, dt=torch.int32)
+        self.copy_stream = torch.cuda.Stream(device=self.device) if pin else None
+
+    def stage(self, b: int, f: int, x: np.ndarray, bbox: np.ndarray, conf: np.ndarray, wh: Tuple[float, float]) -> None:
+        n = x.shape[0]
+        if n > self.M:
+            raise ValueError(f"frame has {n} regions, staging buffers hold {self.M}")
+        self.h_feat[b, f, :n] = torch.from_numpy(x)
+        self.h_box[b, f, :n] = torch.from_numpy(bbox)
+        self.h_conf[b, f, :n] = torch.from_numpy(conf)
+        self.h_conf[b, f, n:] = -1.0                              # never selected: real confidences are positive
+        self.h_wh[b, f, 0], self.h_wh[b, f, 1] = wh
+        self.h_n[b, f] = n
+
+    def stage_video(self, b: int, frame_dir: str, frame_idxs: Sequence[int]) -> None:
+        for f, idx in enumerate(frame_idxs):
+            self.stage(b, f, *read_frame_npz(os.path.join(frame_dir, f"{idx}.npz")))
+
+    def to_device(self):
+        """-> (object [B,F,R,2054] f32, object_mask [B,F,R] f32, object_len [B,F] int32), all on the device."""
+        from . import ops
+        if self.device.type != "cuda":
+            raise ops._lib.DemoVLPHipError("RegionBatcher.to_device needs a ROCm device: there is no CPU fallback")
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_stream(cur)                     # the previous batch's kernels may still read the device buffers
+            d = [t.to(self.device, non_blocking=True) for t in (self.h_feat, self.h_box, self.h_conf, self.h_wh, self.h_n)]
+        cur.wait_stream(self.copy_stream)
+        for t in d:
+            t.record_stream(cur)
+        obj, mask, _order, lens = ops.region_select(d[0], d[1], d[2], d[3], self.R, nvalid=d[4])
+        return obj, mask, lens

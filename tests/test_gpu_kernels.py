@@ -397,3 +397,30 @@ def test_wgrad_grouped_matches_single(dtype):
             single = ops.linear_bwd_weight(probs[i][0], probs[i][1])
             assert rel(o, refs[i]) < tol(dtype), (sel, i)
             assert rel(o, single) < 1e-5, (sel, i)          # same products, possibly a different K split
+
+
+def test_region_batcher_ragged_files_match_reference_pipeline(tmp_path):
+    """.npz files with different region counts -> pinned staging -> device selection == the loader's numpy pipeline
+    (oracle.region_select, itself pinned to the reference by tests/golden/g1), bit for bit."""
+    from helpers import n_raw_for
+    from demovlp_amd.data import RegionBatcher, sample_frame_indices
+    B, F, R = 3, 4, 36
+    rb = RegionBatcher(B, F, R, max_regions=64, device=DEV)
+    want_obj, want_mask, want_len = [], [], []
+    for b in range(B):
+        d = tmp_path / f"vid{b}"
+        d.mkdir()
+        nfiles = F if b == 0 else 9
+        frames = {}
+        for f in range(nfiles):
+            frames[f] = syn.make_frame(10 + b, f, n_raw_for(b + f))          # 28 / 33 / 36 / 50 regions
+            syn.save_frame_npz(str(d / f"{f}.npz"), frames[f])
+        idxs = sample_frame_indices(F, nfiles, "uniform")
+        rb.stage_video(b, str(d), idxs)
+        sel = [frames[i] for i in idxs]
+        o, m, ln, _ = orc.region_select([fr["x"] for fr in sel], [fr["bbox"] for fr in sel], [fr["objects_conf"] for fr in sel], 640, 360, R)
+        want_obj.append(o); want_mask.append(m); want_len.append(ln)
+    obj, mask, lens = rb.to_device()
+    assert np.array_equal(obj.cpu().numpy(), np.stack(want_obj))
+    assert np.array_equal(mask.cpu().numpy().astype(np.float64), np.stack(want_mask))
+    assert lens.cpu().tolist() == want_len

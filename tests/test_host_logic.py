@@ -199,3 +199,39 @@ def test_retrieval_metrics_match_reference_golden():
         for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
             got = fn(sims.copy())
             assert np.allclose([got[k] for k in keys], g[f"{tag}_{name}"], rtol=1e-12, atol=1e-12), (tag, name)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# input side (demovlp_amd/data.py)
+# ------------------------------------------------------------------------------------------------------------------
+def test_shard_indices_equal_torch_distributed_sampler():
+    """Per-rank index lists: identical to DistributedSampler(shuffle, drop_last=True) after set_epoch, ragged sizes included."""
+    from torch.utils.data.distributed import DistributedSampler
+    from demovlp_amd.data import shard_indices
+    for n in (1000, 1003, 17, 8, 5):
+        for world in (1, 2, 8):
+            for shuffle in (True, False):
+                for epoch in (0, 3):
+                    for rank in range(world):
+                        s = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=shuffle, drop_last=True)
+                        s.set_epoch(epoch)
+                        assert list(s) == shard_indices(n, world, rank, epoch, shuffle).tolist(), (n, world, rank, shuffle, epoch)
+
+
+def test_frame_sampling_and_npz_schema(tmp_path):
+    """Frame choice (base/base_dataset.py:82-101) and the per-frame .npz round trip in the reference's schema."""
+    import random
+    from demovlp_amd import synthetic as syn
+    from demovlp_amd.data import read_frame_npz, sample_frame_indices, alternate
+    assert sample_frame_indices(8, 8, "rand") == list(range(8))
+    assert sample_frame_indices(4, 16, "uniform") == [1, 5, 9, 13]            # midpoints of (0,3) (4,7) (8,11) (12,15)
+    assert sample_frame_indices(8, 3, "uniform") == [0, 1, 2]                 # fewer files than segments: min(...) intervals
+    for seed in range(20):
+        idx = sample_frame_indices(8, 30, "rand", random.Random(seed))
+        iv = np.linspace(0, 30, 9).astype(int)
+        assert idx == sorted(idx) and all(iv[i] <= idx[i] < iv[i + 1] - 1 for i in range(8))    # the reference never picks the last frame of an interval
+    fr = syn.make_frame(5, 2, 28)
+    syn.save_frame_npz(str(tmp_path / "2.npz"), fr)
+    x, bbox, conf, wh = read_frame_npz(str(tmp_path / "2.npz"))
+    assert np.array_equal(x, fr["x"]) and np.array_equal(bbox, fr["bbox"]) and np.array_equal(conf, fr["objects_conf"]) and wh == (640.0, 360.0)
+    assert list(alternate([[1, 2, 3], ["a", "b"]])) == [(0, 1), (1, "a"), (0, 2), (1, "b")]
