@@ -516,9 +516,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int64_t M, int64_t N, in
 // whenever the grid still fills the chip.
 template <int ROWS> struct GTile { static constexpr int BYTES = ROWS * 128; };
 
-template <bool FORM_R, int ROWS, int NW>
+// 16 zero bytes in global memory: the LDS-DMA source of every chunk that lies beyond K in a ragged last K tile (the source
+// address of an LDS-DMA is per lane, so zero-filling costs one select, no extra instruction)
+__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// kend < 0: the whole 64-wide K tile is valid; else k >= kend reads zeros (K % 8 == 0 is required)
+template <bool FORM_R, int ROWS, int NW, bool TAIL = false>
 __device__ __forceinline__ void g_issue(char* lds_tile, const bf16* __restrict__ X, int64_t ld, int64_t r0, int64_t k0, int64_t R,
-                                        int wid, int lane) {
+                                        int wid, int lane, int64_t kend = -1) {
     constexpr int PIECES = ROWS / 8, PER_WAVE = PIECES / NW;       // 1-KiB pieces of the tile
     constexpr int CPR = ROWS / 8;                                    // form R: 16-byte chunks per k-row
     constexpr int KPP = 64 / CPR;                                    // form R: k-rows per piece
@@ -531,11 +536,13 @@ __device__ __forceinline__ void g_issue(char* lds_tile, const bf16* __restrict__
             int64_t gr = r0 + rl;
             gr = gr > R - 1 ? R - 1 : gr;
             src = X + gr * ld + k0 + c * 8;
+            if (TAIL && k0 + c * 8 >= kend) src = (const bf16*)g_zero16;
         } else {
             const int kl = KPP * q + lane / CPR, m = ((kl >> 3) & 1) * 4 + (kl & 3), c = (lane % CPR) ^ (m << 1);
             int64_t gr = r0 + c * 8;
             gr = gr > R - 8 ? R - 8 : gr;
             src = X + (k0 + kl) * ld + gr;
+            if (TAIL && k0 + kl >= kend) src = (const bf16*)g_zero16;
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds_tile + q * 1024), 16, 0, 0);
@@ -585,7 +592,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
-    const int64_t nk = (kend - kbeg) / H_BK;
+    const int64_t nk = (kend - kbeg + H_BK - 1) / H_BK;          // the last K tile may be ragged (K % 8 == 0): zero-filled
+    const bool ragged_k = (kend - kbeg) % H_BK != 0;
 
     // per-lane LDS read offsets inside a tile (stage / k-step offsets are added below)
     const int g = lane >> 4, r = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
@@ -601,8 +609,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_glds_kernel(int64_t M, int
 
     auto issue = [&](int64_t kt, int st) {
         char* base = smem_raw + st * STAGE;
-        g_issue<A_R, BM, NW>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane);
-        g_issue<B_R, BN, NW>(base + A_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane);
+        if (ragged_k && kt == nk - 1) {                       // wave-uniform: the common path carries no per-lane K test
+            g_issue<A_R, BM, NW, true>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane, kend);
+            g_issue<B_R, BN, NW, true>(base + A_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane, kend);
+        } else {
+            g_issue<A_R, BM, NW>(base, A, lda, m0, kbeg + kt * H_BK, M, wid, lane);
+            g_issue<B_R, BN, NW>(base + A_B, B, ldb, n0, kbeg + kt * H_BK, N, wid, lane);
+        }
     };
     const int ab = e.flags >> 24;                      // timing ablations (0 in production)
     // DMA instructions one wave issues per K tile (vmcnt bookkeeping of the 3-stage pipeline)
@@ -1263,14 +1276,14 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         static_assert(4 * 64 * 68 * sizeof(float) <= (size_t)4 * H_TILE * sizeof(bf16), "epilogue staging must fit the K-loop buffers");
         // the branch-free loader clamps rows: form-K operands need >= 1 row, form-R operands a row count that is a multiple of 8
         const bool safe = (transA ? (M % 8 != 0 || M < 8) : false) || (transB ? (N % 8 != 0 || N < 8) : false) || K < 8 || K % 8 != 0;
-        const bool dma = !safe && K % H_BK == 0 && g_use_glds;
+        const bool dma = !safe && g_use_glds;                 // (!safe implies K % 8 == 0; a ragged last K tile is zero-filled)
         // 256 x 256 ping-pong kernel: one workgroup per CU, so it wants >= ~a chip of tiles (or a K long enough to split)
         const int64_t ntm8 = cdiv(M, 256), ntn8 = cdiv(N, 256), tiles8 = ntm8 * ntn8 * batch;
         // ... and outputs that fill its tiles: 288 columns would leave the second 256-wide tile 7/8 empty
         const bool fills8 = 10 * M * N >= 8 * (ntm8 * 256) * (ntn8 * 256);
         // ... and a tile count that fills whole rounds of the 256 CUs (300 tiles = 2 rounds for 1.17 rounds of work)
         const bool rounds8 = 10 * tiles8 >= 8 * 256 * cdiv(tiles8, 256);
-        const bool p8 = dma && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 <= 64 && K >= 4096))));
+        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 <= 64 && K >= 4096))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
         // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32
         // slabs (deterministic, no float atomics).
