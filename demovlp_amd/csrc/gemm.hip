@@ -174,6 +174,20 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
     const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
+// 32-bit forms for the 256-row kernel: its blocks are few and short-lived (12 K tiles at K = 768), and the 64-bit divisions
+// of the generic forms sit in front of the first LDS-DMA of every block
+__device__ __forceinline__ int xcd_remap32(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+__device__ __forceinline__ void tile_of32(int wg, int ntm, int ntn, int& tm, int& tn) {
+    const int per_group = 8 * ntn;                      // GROUP_M = 8
+    const int grp = wg / per_group, first = grp * 8;
+    const int gsz = ntm - first < 8 ? ntm - first : 8;
+    const int in = wg - grp * per_group;
+    tn = in / gsz;
+    tm = first + in - tn * gsz;
+}
 
 // Tile order inside that run: groups of GROUP_M row panels, column-major inside a group, so the ~64 workgroups resident
 // on one XCD (32 CUs x 2) cover an ~8 x 8 patch of tiles: 16 operand panels (3 MB at K = 768) stay in the 4 MiB L2
@@ -1056,15 +1070,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
                                                            const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
                                                            Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    int64_t tm_, tn_;
-    tile_of(wg, gridDim.x / ntn, ntn, tm_, tn_);
+    const int wg = xcd_remap32((int)blockIdx.x, (int)gridDim.x);
+    int tm_, tn_;
+    tile_of32(wg, (int)gridDim.x / (int)ntn, (int)ntn, tm_, tn_);
     A += blockIdx.y * e.sA; B += blockIdx.y * e.sB; C += blockIdx.y * e.sC * ((e.flags & EPI_OUT_F32) ? 2 : 1);
     if (e.res) e.res = (const bf16*)e.res + blockIdx.y * e.sRes;
     if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
     const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
-    p8_tile<A_R, B_R>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, tm_ * 256, tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
+    p8_tile<A_R, B_R>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
 }
 
 // Grouped weight gradients: up to P8G_MAX independent dW_p = dY_p^T X_p products (all form R x form R, fp32 out) in ONE
