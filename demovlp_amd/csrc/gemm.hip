@@ -844,12 +844,6 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     const int wr = wid >> 2, wc = wid & 3;
     const int U = 4 * nk;
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     // per-lane source pointers of this wave's two LDS-DMA pieces of every unit kind; they advance one K tile per use
     auto src_ptr = [&](auto form_r, const bf16* X, int64_t ld, int64_t r0, int64_t R, int j) -> const bf16* {
         const int q = wid * 2 + j;                                     // 1-KiB piece of the unit
@@ -884,6 +878,18 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         const int64_t ks = (KIND == 0 || KIND == 3) ? kstepA : kstepB;
         sp[KIND][0] += ks; sp[KIND][1] += ks;
     };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // prologue FIRST: units 0..5 (tile 0 and the first half of tile 1) are requested before anything else is set up, so the
+    // accumulator clears and fragment-offset arithmetic below run under the memory latency instead of in front of it
+    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0);
+    if (nk > 1) { stage(I0{}, 1); stage(I1{}, 1); }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // per-lane fragment-read offsets inside a unit
     const int g = lane >> 4, r = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
@@ -958,8 +964,6 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
     };
 
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     auto phase = [&](auto q_, auto par_, int P) {
         constexpr int Q = decltype(q_)::value, PAR = decltype(par_)::value;
         // ---- load segment: fragment reads of this phase, one unit of prefetch, counted wait for what the NEXT phase reads
@@ -986,10 +990,8 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         __builtin_amdgcn_s_barrier();
     };
 
-    // prologue: units 0..5 (tile 0 and the first half of tile 1), wait for units 0 and 1
-    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0);
-    if (nk > 1) { stage(I0{}, 1); stage(I1{}, 1); p_vmcnt<8>(); }
-    else p_vmcnt<4>();
+    // wait for units 0 and 1 of the prologue issued at the top
+    if (nk > 1) p_vmcnt<8>(); else p_vmcnt<4>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind group 0
     for (int t = 0; t < nk; t += 2) {
