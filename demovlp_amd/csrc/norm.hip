@@ -56,15 +56,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t M, int NC, const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres, T* __restrict__ dx,
-                                                     float* __restrict__ partial /* [grid][2][D] */) {
-    __shared__ float red[4][2][LN_MAXC * 256];
+                                                     float* __restrict__ partial /* [grid][2 + cs][D] */, int cs) {
+    // cs: also emit the column sums of the OUTPUT dx (third plane): dx feeds a Linear whose bias gradient is exactly that sum,
+    // which saves a separate pass over dx (values are summed as stored, i.e. after rounding to T, like that pass would)
+    extern __shared__ __attribute__((aligned(16))) float red_[];      // [4 waves][2 + cs planes][D]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int D = NC * 256;
-    float dg[LN_MAXC][4], db[LN_MAXC][4], gm[LN_MAXC][4];
+    float dg[LN_MAXC][4], db[LN_MAXC][4], gm[LN_MAXC][4], dc[LN_MAXC][4];
     for (int c = 0; c < NC; ++c) {
         Vec4<float>::load(gamma + c * 256 + lane * 4, gm[c]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; dc[c][j] = 0.f; }
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < M; row += (int64_t)gridDim.x * 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -97,16 +99,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t M, int NC, const T*
                 for (int j = 0; j < 4; ++j) o[j] += r[j];
             }
             Vec4<T>::store(dx + row * D + c * 256 + lane * 4, o);
+            if (cs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dc[c][j] += to_f(from_f<T>(o[j]));
+            }
         }
     }
+    const int planes = 2 + (cs ? 1 : 0);
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { red[wid][0][c * 256 + lane * 4 + j] = dg[c][j]; red[wid][1][c * 256 + lane * 4 + j] = db[c][j]; }
+        for (int j = 0; j < 4; ++j) {
+            const int col = c * 256 + lane * 4 + j;
+            red_[(wid * planes + 0) * D + col] = dg[c][j]; red_[(wid * planes + 1) * D + col] = db[c][j];
+            if (cs) red_[(wid * planes + 2) * D + col] = dc[c][j];
+        }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
-        const int w = i / D, col = i % D;
-        partial[(int64_t)blockIdx.x * 2 * D + i] = red[0][w][col] + red[1][w][col] + red[2][w][col] + red[3][w][col];
-    }
+    for (int i = threadIdx.x; i < planes * D; i += 256)
+        partial[(int64_t)blockIdx.x * planes * D + i] = red_[i] + red_[planes * D + i] + red_[2 * planes * D + i] + red_[3 * planes * D + i];
 }
 
 // out[g][c] (+)= sum_p in[(g*P + p)*C + c].  32 columns x 8 partial-sum lanes per workgroup: the P-loop is split
@@ -302,24 +311,33 @@ extern "C" int dvlp_reduce_flush(void* stream) {
 // workspace: fp32 [(dvlp_layernorm_bwd_blocks(M) + 1) * 2 * D].  dgamma/dbeta are overwritten (accumulate=0) or added to.
 extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv(M, 4); return b < 1024 ? b : 1024; }
 
+extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
+                           int64_t gstride, float* out, float* workspace, int accumulate, void* stream);
+
 extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace,
-                                  int accumulate, void* stream) {
+                                  int accumulate, float* dx_colsum, void* stream) {
     dvlp_clear_status();
     if (D % 256 || D > 256 * LN_MAXC || M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = dvlp_layernorm_bwd_blocks(M);
     dim3 grid((unsigned)nb), block(256);
     std::unique_lock<std::mutex> lk(g_rd.mu);
-    float* dws = (accumulate & 2) ? rd_reserve(nb * 2 * D, 2) : nullptr;
+    // dx_colsum (the bias gradient of the Linear that dx feeds) rides along only on the deferred path: a third partial plane
+    const int cs = (dx_colsum && (accumulate & 2)) ? 1 : 0;
+    float* dws = (accumulate & 2) ? rd_reserve(nb * (2 + cs) * D, 2 + cs) : nullptr;
+    const int csk = dws ? cs : 0;
     if (dws) workspace = dws;
-    if (dtype == DVLP_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, M, (int)(D / 256), (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, workspace);
-    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, st, M, (int)(D / 256), (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, workspace);
+    const size_t ldsb = (size_t)4 * (2 + csk) * D * sizeof(float);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, ldsb, st, M, (int)(D / 256), (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, workspace, csk);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, ldsb, st, M, (int)(D / 256), (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, workspace, csk);
     else return DVLP_ERR_DTYPE;
-    // partial layout [nb][2][D]: reduce the two halves separately (stride 2D between blocks)
+    // partial layout [nb][2 (+1)][D]: reduce the planes separately (stride = planes * D between blocks)
     if (dws) {
-        if (dbeta == dgamma + D) rd_push(dws, dgamma, nb, 2 * D, 2 * D, accumulate & 1);
-        else { rd_push(dws, dgamma, nb, D, 2 * D, accumulate & 1); rd_push(dws + D, dbeta, nb, D, 2 * D, accumulate & 1); }
+        const int64_t pl = (2 + csk) * D;
+        if (dbeta == dgamma + D) rd_push(dws, dgamma, nb, 2 * D, pl, accumulate & 1);
+        else { rd_push(dws, dgamma, nb, D, pl, accumulate & 1); rd_push(dws + D, dbeta, nb, D, pl, accumulate & 1); }
+        if (csk) rd_push(dws + 2 * D, dx_colsum, nb, D, pl, 0);
         return dvlp_launch_status();
     }
     lk.unlock();
@@ -331,7 +349,10 @@ extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* d
         hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(D, 32), 1), dim3(256), 0, st, (int64_t)1, D, workspace + nb * 2 * D, dgamma, accumulate);
         hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(D, 32), 1), dim3(256), 0, st, (int64_t)1, D, workspace + nb * 2 * D + D, dbeta, accumulate);
     }
-    return dvlp_launch_status();
+    if (int rc = dvlp_launch_status()) return rc;
+    // not deferred: the column sums of dx are a plain second pass (the LayerNorm workspace is free again in stream order)
+    if (dx_colsum) return dvlp_colsum(dtype, M, D, dx, D, M, 0, 1, 0, dx_colsum, workspace, 0, stream);
+    return DVLP_OK;
 }
 
 // out[g][n] (+)= sum_m x_g[m][n]   (bias / embedding-table gradients).  Row m of group g is at

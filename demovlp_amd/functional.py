@@ -102,6 +102,7 @@ def _wgrad_group(items):
 
 
 FUSE_TEXT_QKV = os.environ.get("DVLP_NO_FUSED_QKV") is None      # developer switch for A/B timing
+FUSE_LN_COLSUM = os.environ.get("DVLP_NO_LN_COLSUM") is None     # developer switch for A/B timing
 
 
 def _stacked(ts):
@@ -139,11 +140,18 @@ def _bgrad(dy2d, param):
         return ops.colsum(dy2d, out=gb, defer=gb is not None)
 
 
-def _ln_bwd(dy2d, x2d, w, b, mean, rstd, dres=None):
-    """LayerNorm backward with dgamma / dbeta going to the parameters' arena slices (deferred final reduction) when attached."""
+def _ln_bwd(dy2d, x2d, w, b, mean, rstd, dres=None, bias_of_next=None):
+    """LayerNorm backward with dgamma / dbeta going to the parameters' arena slices (deferred final reduction) when attached.
+    ``bias_of_next``: bias parameter of the Linear that consumed the LayerNorm's INPUT... i.e. whose output gradient is the dx
+    computed here: its gradient (column sums of dx) then comes out of the same kernel.  Returns (dx, dgamma, dbeta, dbias|None)."""
     gw, gb = _grad_buf(w), _grad_buf(b)
-    return ops.layernorm_bwd(dy2d, x2d, w.detach(), mean, rstd, dres=dres, out_gamma=gw, out_beta=gb,
-                             defer=gw is not None and gb is not None)
+    gnext = _grad_buf(bias_of_next) if bias_of_next is not None else None
+    fused = gnext is not None and gw is not None and gb is not None and FUSE_LN_COLSUM
+    dx, dg, db = ops.layernorm_bwd(dy2d, x2d, w.detach(), mean, rstd, dres=dres, out_gamma=gw, out_beta=gb,
+                                   defer=gw is not None and gb is not None, dx_colsum=gnext if fused else None)
+    if bias_of_next is None:
+        return dx, dg, db
+    return dx, dg, db, (gnext if fused else _bgrad(dx, bias_of_next))
 
 
 def _into(param, value):
@@ -264,8 +272,7 @@ class VitBlockFn(torch.autograd.Function):
         dpre = ops.linear_bwd_input(dy2, SHADOWS.get(f2w, cd), gelu_pre=pre)
         df1b = _bgrad(dpre, f1b)
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
-        dx1, dn2w, dn2b = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2)
-        dpb = _bgrad(dx1, pb)
+        dx1, dn2w, dn2b, dpb = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2, bias_of_next=pb)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
         dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R)
         dqkvb = _bgrad(dqkv, qkvb)
@@ -350,13 +357,11 @@ class BertLayerFn(torch.autograd.Function):
         B, L = ctx.dims
         cd = x2.dtype
         dy2 = dy.reshape(B * L, -1).contiguous()
-        ds2, dl2w, dl2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2)
-        df2b = _bgrad(ds2, f2b)
+        ds2, dl2w, dl2b, df2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2, bias_of_next=f2b)
         dpre = ops.linear_bwd_input(ds2, SHADOWS.get(f2w, cd), gelu_pre=pre)
         df1b = _bgrad(dpre, f1b)
         dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
-        ds1, dl1w, dl1b = _ln_bwd(dx1, s1, l1w, l1b, m1, r1)
-        dob = _bgrad(ds1, ob)
+        ds1, dl1w, dl1b, dob = _ln_bwd(dx1, s1, l1w, l1b, m1, r1, bias_of_next=ob)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))
         fused = _fused_qkv(qw, qb, kw, kb, vw, vb, cd) if ctx.fused else None
         if fused is not None:

@@ -233,7 +233,7 @@ def layernorm_fwd(x2d, gamma, beta, eps, want_relu=False):
     return y, yr, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_beta=None, defer=False):
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_beta=None, defer=False, dx_colsum=None):
     """``out_gamma`` / ``out_beta``: optional fp32 destinations (e.g. gradient-arena slices); contiguous pairs reduce in one launch.
     ``defer``: dgamma / dbeta are not read before flush_reductions()."""
     M, D = x2d.shape
@@ -245,7 +245,7 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dres=None, out_gamma=None, out_b
         dgamma, dbeta = gb[:D], gb[D:]
     ws = _workspace("ln", (call("dvlp_layernorm_bwd_blocks", M) + 1) * 2 * D, x2d.device)
     call("dvlp_layernorm_bwd", dt(x2d), M, D, p(dy2d), p(x2d), p(gamma), p(mean), p(rstd), p(dres), p(dx), p(dgamma), p(dbeta),
-         p(ws), 2 if defer else 0, stream())
+         p(ws), 2 if defer else 0, p(dx_colsum), stream())
     return dx, dgamma, dbeta
 
 

@@ -75,9 +75,11 @@ int dvlp_attention_ablate(int bits);
 int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,
                        void* y_relu, float* mean, float* rstd, void* stream);
 int64_t dvlp_layernorm_bwd_blocks(int64_t M);
+/* dx_colsum (optional): fp32 [D] <- column sums of dx, i.e. the bias gradient of the Linear that dx feeds (nn.Linear backward
+   after the LayerNorm's); produced by the same kernel on the deferred path, by a dvlp_colsum pass otherwise */
 int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace, int accumulate,
-                       void* stream);
+                       float* dx_colsum, void* stream);
 /* Deferred second stages.  dvlp_layernorm_bwd / dvlp_colsum called with (accumulate | 2) -- "nobody reads the result before
    the flush" -- park their partial sums in `workspace` and queue the final column reduction; dvlp_reduce_flush runs every
    queued reduction as ONE launch (a training step otherwise pays ~125 ten-microsecond launches for them).  The table is

@@ -370,15 +370,23 @@ def test_deferred_reductions_match_immediate():
             split_g, split_b = torch.full((D,), 1.0, device=DEV), torch.full((D,), 2.0, device=DEV)
             dx1, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, out_gamma=gb[:D], out_beta=gb[D:], defer=True)
             dx2, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, out_gamma=split_g, out_beta=split_b, defer=True)
+            # the bias gradient of the Linear that dx feeds (= column sums of dx as stored) out of the same kernel
+            cs, g3 = torch.full((D,), 9.0, device=DEV), torch.empty(2 * D, device=DEV)
+            dx3, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, out_gamma=g3[:D], out_beta=g3[D:], defer=True, dx_colsum=cs)
             assert float(outs[0][0]) == 7.0                      # really deferred: nothing written yet
             ops.flush_reductions()
             for o, w in zip(outs, want_cs):
                 assert torch.equal(o, w)
             assert torch.equal(gb[:D], dg0) and torch.equal(gb[D:], db0)
             assert torch.equal(split_g, dg0) and torch.equal(split_b, db0)
-            assert torch.equal(dx1, dx0) and torch.equal(dx2, dx0)
+            assert torch.equal(dx1, dx0) and torch.equal(dx2, dx0) and torch.equal(dx3, dx0)
+            assert torch.equal(g3[:D], dg0) and torch.equal(g3[D:], db0)
+            assert rel(cs, dx0.float().sum(0)) < 1e-5
     finally:
         ops.disable_deferred_reductions()
+    cs = torch.empty(D, device=DEV)                              # not deferred: same result through the fallback pass
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx_colsum=cs)
+    assert torch.equal(cs, ops.colsum(dx0))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
