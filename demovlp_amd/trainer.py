@@ -164,6 +164,7 @@ class GradReducer:
                 self.bucket_of[i] = b
         if arena.flat_g.is_cuda:
             ops.enable_deferred_reductions(arena.flat_g.device)
+        self._issue_stream = None
         self.expected = None       # per bucket: set of param indices known to get gradients (learned on step 1)
         self._seen = set()
         self._pending = None
@@ -190,9 +191,14 @@ class GradReducer:
         # with weight gradients on the side stream, the collective must be ordered after BOTH streams: issue it from the
         # side stream after making that wait for the main stream (RCCL's own stream then waits for the side stream)
         if Fn.OVERLAP_WGRAD and self.arena.flat_g.is_cuda:
-            side = ops.side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            # issue from a third stream that waits for both compute streams: neither of them stalls behind the other (making
+            # the side stream wait for the main one here serialised the weight-gradient GEMMs it exists to overlap)
+            if self._issue_stream is None:
+                self._issue_stream = torch.cuda.Stream(device=self.arena.flat_g.device)
+            cs = self._issue_stream
+            cs.wait_stream(torch.cuda.current_stream())
+            cs.wait_stream(ops.side_stream())
+            with torch.cuda.stream(cs):
                 h = dist.all_reduce(self.arena.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             h = dist.all_reduce(self.arena.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

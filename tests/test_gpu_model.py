@@ -178,12 +178,14 @@ def test_arena_paths_give_the_same_gradients(dtype):
     assert worst[0][0] <= tol, worst[:8]
 
 
-def _dp2_worker(rank, world, port, q):
+def _dp2_worker(rank, world, port, q, overlap=0):
     """One data-parallel rank (both ranks share cuda:0; gloo carries the gradient buckets) running the real HIP step."""
     import os
     import torch.distributed as dist
+    import demovlp_amd.functional as Fn
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    Fn.OVERLAP_WGRAD = overlap
     try:
         F, R, B = 8, 36, 2
         model = build(F, R)
@@ -209,7 +211,8 @@ def _dp2_batch(F, R, B, rank):
             "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
 
 
-def test_two_rank_data_parallel_step_matches_averaged_gradients():
+@pytest.mark.parametrize("overlap", [0, 2], ids=["one-stream", "wgrad-side-stream"])
+def test_two_rank_data_parallel_step_matches_averaged_gradients(overlap):
     """The multi-GPU path on one GPU: two processes, each its own batch, GradReducer all-reducing arena buckets from the
     post-accumulate hooks (tail bucket after the deferred flush), 1/world folded into fused AdamW.  Both ranks must end
     with the same parameters, equal to a single process that averages the two batches' gradients itself."""
@@ -218,7 +221,7 @@ def test_two_rank_data_parallel_step_matches_averaged_gradients():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
