@@ -973,8 +973,8 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
     const int64_t brow0 = (int64_t)b * a.N;
     const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; const bf16* dout = (const bf16*)a.dout;
     bf16* dq = (bf16*)a.dq; bf16* dk = (bf16*)a.dk; bf16* dv = (bf16*)a.dv;
-    bf16* Ks = (bf16*)smraw; bf16* Qs = Ks + ROWS * VLD; bf16* Gs = Qs + ROWS * VLD;
-    float* stats = (float*)(Gs + ROWS * VLD);      // [ROWS][3]: row max, 1/row sum, D = sum_k P dP  (written by layout 1)
+    bf16* Ks = (bf16*)smraw; bf16* Qs = Ks + ROWS * VLD; bf16* Gs = Qs + ROWS * VLD; bf16* Vs = Gs + ROWS * VLD;
+    float* stats = (float*)(Vs + ROWS * VLD);      // [ROWS][3]: row max, 1/row sum, D = sum_k P dP  (written by layout 1)
     // cooperative staging: wave w copies rows [w*ROWS/4, (w+1)*ROWS/4) of each tile
     {
         const Seg all = sg;
@@ -982,23 +982,24 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
         for (int it = 0; it < ROWS / 32; ++it) {
             const int row = wid * (ROWS / 4) + it * 8 + (lane >> 3), ch = lane & 7;
             const int tok = all.tok_k(row);
-            uint4 kv = make_uint4(0u, 0u, 0u, 0u), qv = kv, gv = kv;
+            uint4 kv = make_uint4(0u, 0u, 0u, 0u), qv = kv, gv = kv, vv = kv;
             if (tok >= 0) {
                 kv = *(const uint4*)(k + (brow0 + tok) * a.ld + h * HD + ch * 8);
                 qv = *(const uint4*)(q + (brow0 + tok) * a.ld + h * HD + ch * 8);
                 gv = *(const uint4*)(dout + (brow0 + tok) * a.ldo + h * HD + ch * 8);
+                vv = *(const uint4*)(v + (brow0 + tok) * a.ld + h * HD + ch * 8);
             }
             *(uint4*)&Ks[row * VLD + ch * 8] = kv; *(uint4*)&Qs[row * VLD + ch * 8] = qv; *(uint4*)&Gs[row * VLD + ch * 8] = gv;
+            *(uint4*)&Vs[row * VLD + ch * 8] = vv;
         }
     }
     __syncthreads();
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // row fragments of tile t (16 rows, both k-steps) straight from the LDS tiles (row-major, 16-byte reads)
     auto rowfrag = [&](const bf16* T, int t, int ks) { return *(const bf16x8*)&T[(16 * t + c) * VLD + 32 * ks + 8 * g]; };
-    auto vfrag = [&](int t, int ks) {          // V rows are not staged: read them from global
-        int tok = sg.tok_k(16 * t + c); tok = tok < 0 ? 0 : tok;
-        return *(const bf16x8*)(v + (brow0 + tok) * a.ld + h * HD + 32 * ks + 8 * g);
-    };
+    // (V is staged like the others: fetching its fragments from global memory inside the tile loops put a memory round trip
+    //  in front of every MFMA group)
+    auto vfrag = [&](int t, int ks) { return rowfrag(Vs, t, ks); };
     // ---------------- layout 1: this wave's query tiles -> dQ ----------------
 #pragma unroll 1
     for (int qi = 0; qi < 2; ++qi) {
@@ -1233,7 +1234,7 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
         }
         if (mode == 1 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0) {
             const int nt = (int)cdiv(N, 16);
-#define MFULL(NT_) do { const size_t l_ = (size_t)3 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16) + (size_t)16 * ((NT_ + 1) & ~1) * 3 * sizeof(float); \
+#define MFULL(NT_) do { const size_t l_ = (size_t)4 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16) + (size_t)16 * ((NT_ + 1) & ~1) * 3 * sizeof(float); \
             (void)hipFuncSetAttribute((const void*)mattn_bwd_full_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             hipLaunchKernelGGL((mattn_bwd_full_kernel<NT_>), dim3((unsigned)H, (unsigned)B), block, l_, st, a); done = true; } while (0)
             if (nt == 7) MFULL(7);
