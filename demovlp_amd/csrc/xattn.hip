@@ -658,17 +658,35 @@ __global__ __launch_bounds__(256) void xcos_fwd_kernel(CosArgs a) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = blockIdx.x, i = blockIdx.y;
     float acc1 = 0.f, acc2 = 0.f;
-    for (int w = wid; w < a.W; w += 4) {
-        const int64_t r = ((int64_t)i * a.Bj + j) * a.Wp + w;
-        float dot, nb;
-        acc1 += row_cos<T>((const T*)a.Qraw + ((int64_t)j * a.W + w) * XD, (const T*)a.wc + r * XD, lane, dot, nb);
-        if (lane == 0) { a.st1[r * 2] = dot; a.st1[r * 2 + 1] = nb; }
-    }
-    for (int g = wid; g < a.G; g += 4) {
-        const int64_t r = ((int64_t)j * a.Bi + i) * a.G + g;
-        float dot, nb;
-        acc2 += row_cos<T>((const T*)a.Craw + ((int64_t)i * a.G + g) * XD, (const T*)a.wc2 + r * XD, lane, dot, nb);
-        if (lane == 0) { a.st2[r * 2] = dot; a.st2[r * 2 + 1] = nb; }
+    // rows in batches of UB per wave with all of a batch's loads issued before its first reduction: a row at a time the loop
+    // is a chain of (load -> three wave reductions) and the kernel ran at half its HBM roofline
+    constexpr int UB = 4;
+    auto sweep = [&](const T* raw0, const T* ctx0, float* st, int n, float& acc) {
+        for (int r0 = wid; r0 < n; r0 += 4 * UB) {
+            float x[UB][4], y[UB][4];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int r = r0 + 4 * u < n ? r0 + 4 * u : n - 1;
+                ld4<T>(raw0 + (int64_t)r * XD + lane * 4, x[u]); ld4<T>(ctx0 + (int64_t)r * XD + lane * 4, y[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int r = r0 + 4 * u;
+                float d = 0.f, nx = 0.f, ny = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { d += x[u][t] * y[u][t]; nx += x[u][t] * x[u][t]; ny += y[u][t] * y[u][t]; }
+                d = wave_sum(d); nx = sqrtf(wave_sum(nx)); ny = sqrtf(wave_sum(ny));
+                if (r < n) {
+                    acc += d / fmaxf(nx * ny, 1e-8f);                       // cosine_similarity (loss.py:286-291)
+                    if (lane == 0) { st[(int64_t)r * 2] = d; st[(int64_t)r * 2 + 1] = ny; }
+                }
+            }
+        }
+    };
+    {
+        const int64_t r1 = ((int64_t)i * a.Bj + j) * a.Wp, r2 = ((int64_t)j * a.Bi + i) * a.G;
+        sweep((const T*)a.Qraw + (int64_t)j * a.W * XD, (const T*)a.wc + r1 * XD, a.st1 + r1 * 2, a.W, acc1);
+        sweep((const T*)a.Craw + (int64_t)i * a.G * XD, (const T*)a.wc2 + r2 * XD, a.st2 + r2 * 2, a.G, acc2);
     }
     if (lane == 0) red[wid] = acc1 / (float)a.W + acc2 / (float)a.G;       // means include padded rows (loss.py:318, 327)
     __syncthreads();
