@@ -27,6 +27,7 @@ struct Epi {
     float alpha;
     int64_t sA, sB, sC, sRes, sAux;   // batch strides in elements (blockIdx.y = batch index)
     int vec;                          // C / res / aux rows are 16-byte aligned: the bf16 epilogue may use 8-wide accesses
+    float* csum;                      // 256-row kernel: [2 * row tiles][N] partial column sums of the stored output, or null
 };
 
 // Scalar epilogue.  Deliberately NOT inlined: it is called 64x per thread from the f32 kernel and from the ragged-edge path
@@ -164,7 +165,7 @@ __device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ 
     }
     bf16x8 o;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
+    for (int t = 0; t < 8; ++t) { o[t] = (bf16)v[t]; v[t] = (float)o[t]; }     // v <- the values as stored (column-sum fusion)
     *(bf16x8*)Cp = o;
 }
 
@@ -1020,6 +1021,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     float4 bb0 = make_float4(0.f, 0.f, 0.f, 0.f), bb1 = bb0;
     if (whole && e.bias) { bb0 = *(const float4*)(e.bias + ncol); bb1 = *(const float4*)(e.bias + ncol + 4); }
     bf16x8 pr[4], pa[4];
+    float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // e.csum: this lane's column sums over the rows it stores
     auto mrow_of = [&](int hp) { return m0 + 128 * (hp >> 1) + 64 * wr + 32 * (hp & 1); };
     auto preload = [&](int hp) {
         if (!whole) return;
@@ -1057,11 +1059,27 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
                 bf16x8 r = {}, a = {};
                 if (has_res) r = Rs[it * 64 + lane];
                 if (has_aux) a = As[it * 64 + lane];
-                if (m < M) epi_store8_pre(e, C, ldc, m, ncol, v, bb0, bb1, r, a);
+                if (m < M) {
+                    epi_store8_pre(e, C, ldc, m, ncol, v, bb0, bb1, r, a);
+                    if (e.csum) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) cs8[t] += v[t];
+                    }
+                }
             }
         } else {
             const Epi ec = e;   // see epi_store8: keep the kernel's own Epi out of scratch
             p8_store_ragged(ec, C, ldc, Ct, mrow0, ncol, M, N, slab_out, lane);
+        }
+    }
+    if (e.csum && whole) {
+        // the eight lanes that share lane & 7 hold the same 8 columns for different rows: combine, one partial row per wave
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cs8[t] = stride8_sum(cs8[t]);
+        if (rsub == 0) {
+            float* dst = e.csum + ((m0 >> 8) * 2 + wr) * N + ncol;
+            *(float4*)dst = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
+            *(float4*)(dst + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
         }
     }
 }
@@ -1112,7 +1130,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_group_kernel(P8Group g, int 
     int64_t tm_, tn_;
     tile_of(wg % g.tiles[p], g.tiles[p] / g.ntn[p], g.ntn[p], tm_, tn_);
     const int64_t kbeg = z * g.kchunk[p], kend = kbeg + g.kchunk[p] < g.K[p] ? kbeg + g.kchunk[p] : g.K[p];
-    Epi e{nullptr, nullptr, nullptr, 0, 0, flags | EPI_OUT_F32, 1.0f, 0, 0, 0, 0, 0, 1};
+    Epi e{nullptr, nullptr, nullptr, 0, 0, flags | EPI_OUT_F32, 1.0f, 0, 0, 0, 0, 0, 1, nullptr};
     e.vec = (g.N[p] % 4 == 0) ? 1 : 0;
     float* slab_out = g.S[p] > 1 ? g.slab[p] + (int64_t)z * g.M[p] * g.N[p] : nullptr;
     p8_tile<true, true>(smem_raw, g.M[p], g.N[p], g.A[p], g.lda[p], g.B[p], g.ldb[p], (bf16*)g.C[p], g.N[p], e, tm_ * 256, tn_ * 256, kbeg,
@@ -1249,15 +1267,26 @@ extern "C" int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t*
     return DVLP_OK;
 }
 
+// ---- column sums of the NEXT GEMM's output (dvlp_gemm_colsum_next): the bias gradient of the Linear that consumes it ----
+float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out);      // norm.hip: deferred-reduction queue
+extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
+                           int64_t gstride, float* out, float* workspace, int accumulate, void* stream);
+extern "C" int64_t dvlp_colsum_chunks(int64_t M);
+static thread_local float* t_colsum_next = nullptr;
+extern "C" int dvlp_gemm_colsum_next(float* dst) { t_colsum_next = dst; return DVLP_OK; }
+
 extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                                  const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
                                  void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
                                  int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream) {
     dvlp_clear_status();
+    float* const csum_dst = t_colsum_next;      // column sums of this GEMM's output requested (dvlp_gemm_colsum_next)
+    t_colsum_next = nullptr;
+    bool csum_fused = false;
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return DVLP_ERR_SHAPE;
     if ((flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD)) && !aux) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    Epi e{bias, res, aux, ldres, ldaux, flags | (g_ablate << 24), alpha, strideA, strideB, strideC, strideRes, strideAux, 0};
+    Epi e{bias, res, aux, ldres, ldaux, flags | (g_ablate << 24), alpha, strideA, strideB, strideC, strideRes, strideAux, 0, nullptr};
     {
         const int64_t cal = (flags & EPI_OUT_F32) ? 4 : 8;      // elements per 16 bytes of C
         bool v = (ldc % cal == 0) && ((uintptr_t)C % 16 == 0) && (strideC % cal == 0);
@@ -1317,6 +1346,10 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;
         S = cdiv(K, kchunk);
         float* slab = S > 1 ? g_ws : nullptr;
+        if (csum_dst && p8 && batch == 1 && S == 1 && e.vec && N % 256 == 0 && !(flags & EPI_OUT_F32)) {
+            e.csum = dvlp_rd_reserve_push(2 * ntm8, N, csum_dst);      // partial rows: (row tile, upper / lower wave group)
+            csum_fused = e.csum != nullptr;
+        }
         dim3 grid((unsigned)(ntm * ntn), (unsigned)batch, (unsigned)S), block(256);
         // > 64 KiB of dynamic LDS must be opted into once per kernel
 #define LAUNCH_BF16_(AR, BR, SF) do { static bool once = false; if (!once) { once = true; \
@@ -1356,6 +1389,12 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         return DVLP_ERR_DTYPE;
     }
     if (g_prof) { (void)hipEventRecord(rec.b, st); g_recs.push_back(rec); }
+    if (csum_dst && !csum_fused) {            // not fused: a plain column-sum pass over the stored output (batch 1 only)
+        if (int rc = dvlp_launch_status()) return rc;
+        const WsEntry w2 = ws_for(stream);
+        if (batch != 1 || (flags & EPI_OUT_F32) || !w2.ptr || dvlp_colsum_chunks(M) * N * 4 > w2.bytes) return DVLP_ERR_SHAPE;
+        return dvlp_colsum(dtype, M, N, C, ldc, M, 0, 1, 0, csum_dst, w2.ptr, 0, stream);
+    }
     return dvlp_launch_status();
 }
 

@@ -262,6 +262,14 @@ static void rd_push(const float* in, float* out, int64_t P, int64_t C, int64_t s
     g_rd.nblk += (int)cdiv(C, 32);
 }
 
+// used by the GEMM's fused column sums (gemm.hip): reserve partial space / queue a reduction under the queue's lock
+float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out) {
+    std::lock_guard<std::mutex> lk(g_rd.mu);
+    float* p = rd_reserve(P * C, 1);
+    if (p) rd_push(p, out, P, C, C, 0);
+    return p;
+}
+
 __global__ __launch_bounds__(256) void reduce_batched_kernel(const RItem* __restrict__ items, int nitems) {
     __shared__ float red[8][33];
     // which item owns this block: binary search over the items' first-block prefix (<= ~10 steps, wave-uniform)

@@ -103,6 +103,7 @@ def _wgrad_group(items):
 
 FUSE_TEXT_QKV = os.environ.get("DVLP_NO_FUSED_QKV") is None      # developer switch for A/B timing
 FUSE_LN_COLSUM = os.environ.get("DVLP_NO_LN_COLSUM") is None     # developer switch for A/B timing
+FUSE_GEMM_COLSUM = os.environ.get("DVLP_NO_GEMM_COLSUM") is None  # developer switch for A/B timing
 
 
 def _stacked(ts):
@@ -138,6 +139,16 @@ def _bgrad(dy2d, param):
     with _Side(dy2d):
         # written into the gradient arena: nobody reads it before the trainer's flush, so the final reduction may be batched
         return ops.colsum(dy2d, out=gb, defer=gb is not None)
+
+
+def _dx_with_bias_grad(dy2d, w_next, gelu_pre, bias):
+    """d(pre-activation) = (dy W_next) * gelu'(pre) together with the gradient of the bias that was added to that pre-activation
+    (its column sums): out of one GEMM when the bias gradient lives in an arena, else GEMM + column-sum pass."""
+    gb = _grad_buf(bias)
+    if gb is not None and FUSE_GEMM_COLSUM:
+        return ops.linear_bwd_input(dy2d, w_next, gelu_pre=gelu_pre, colsum_to=gb), gb
+    dpre = ops.linear_bwd_input(dy2d, w_next, gelu_pre=gelu_pre)
+    return dpre, _bgrad(dpre, bias)
 
 
 def _ln_bwd(dy2d, x2d, w, b, mean, rstd, dres=None, bias_of_next=None):
@@ -269,8 +280,7 @@ class VitBlockFn(torch.autograd.Function):
         cd = x2.dtype
         dy2 = dy.reshape(B * N, -1).contiguous()
         df2b = _bgrad(dy2, f2b)
-        dpre = ops.linear_bwd_input(dy2, SHADOWS.get(f2w, cd), gelu_pre=pre)
-        df1b = _bgrad(dpre, f1b)
+        dpre, df1b = _dx_with_bias_grad(dy2, SHADOWS.get(f2w, cd), pre, f1b)
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
         dx1, dn2w, dn2b, dpb = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2, bias_of_next=pb)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
@@ -358,8 +368,7 @@ class BertLayerFn(torch.autograd.Function):
         cd = x2.dtype
         dy2 = dy.reshape(B * L, -1).contiguous()
         ds2, dl2w, dl2b, df2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2, bias_of_next=f2b)
-        dpre = ops.linear_bwd_input(ds2, SHADOWS.get(f2w, cd), gelu_pre=pre)
-        df1b = _bgrad(dpre, f1b)
+        dpre, df1b = _dx_with_bias_grad(ds2, SHADOWS.get(f2w, cd), pre, f1b)
         dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
         ds1, dl1w, dl1b, dob = _ln_bwd(dx1, s1, l1w, l1b, m1, r1, bias_of_next=ob)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))

@@ -93,8 +93,10 @@ def linear_fwd(x2d, w, bias=None, res=None, gelu_aux=None):
     return gemm(x2d, w, M, N, K, bias=bias, res=res, aux=gelu_aux, flags=EPI_GELU if gelu_aux is not None else 0)
 
 
-def linear_bwd_input(dy2d, w, *, res=None, gelu_pre=None, relu_pre=None, out=None, accumulate=False):
-    """dx = dy W  (optionally * gelu'(pre) or masked by pre > 0, + res, or accumulated onto ``out``)."""
+def linear_bwd_input(dy2d, w, *, res=None, gelu_pre=None, relu_pre=None, out=None, accumulate=False, colsum_to=None):
+    """dx = dy W  (optionally * gelu'(pre) or masked by pre > 0, + res, or accumulated onto ``out``).
+    ``colsum_to``: fp32 [K] destination for the column sums of dx (the bias gradient of the Linear that produced this GEMM's
+    input side); fused into the GEMM epilogue on the deferred path -- final after :func:`flush_reductions` then."""
     M, N = dy2d.shape
     K = w.shape[1]
     flags, aux = 0, None
@@ -105,6 +107,10 @@ def linear_bwd_input(dy2d, w, *, res=None, gelu_pre=None, relu_pre=None, out=Non
     if accumulate:
         flags |= EPI_ACCUM
     # A = dy [M x N] (k = N contiguous), B(kin, n) = W[n][kin] -> form R with ld = K
+    if colsum_to is not None:
+        assert colsum_to.dtype == torch.float32 and colsum_to.numel() == K and not accumulate
+        ensure_gemm_workspace(dy2d.device)
+        call("dvlp_gemm_colsum_next", p(colsum_to))
     return gemm(dy2d, w, M, K, N, trans_b=True, ldb=K, bias=None, res=res, aux=aux, flags=flags, out=out)
 
 

@@ -47,6 +47,11 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
    host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
+/* The next dvlp_gemm issued by this host thread also produces dst[N] (fp32) = column sums of its stored output C -- e.g. the bias
+   gradient of fc1 out of the GEMM that computes d(pre-activation).  Fused into the 256 x 256 kernel's epilogue when the deferred
+   reductions (dvlp_reduce_defer) are on -- final after dvlp_reduce_flush --, otherwise a dvlp_colsum pass right after the GEMM
+   (needs the split-K workspace as scratch). */
+int dvlp_gemm_colsum_next(float* dst);
 /* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
 int dvlp_gemm_variant(int use_lds_dma);
 /* TIMING-ONLY ablation of the LDS-DMA kernel's K loop (1 no DMA, 2 no fragment reads, 4 no MFMA); 0 in production */

@@ -432,3 +432,25 @@ def test_region_batcher_ragged_files_match_reference_pipeline(tmp_path):
     assert np.array_equal(obj.cpu().numpy(), np.stack(want_obj))
     assert np.array_equal(mask.cpu().numpy().astype(np.float64), np.stack(want_mask))
     assert lens.cpu().tolist() == want_len
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(4160, 768, 3072), (1000, 768, 768), (777, 520, 264)])
+def test_gemm_fused_column_sums(dtype, M, N, K):
+    """dvlp_gemm_colsum_next: column sums of the GEMM's stored output, fused into the 256-row epilogue on the deferred path and
+    by a plain pass otherwise -- both equal ops.colsum of the output."""
+    dy, w, pre = rnd(M, N, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.05), rnd(M, K, dtype=dtype, seed=2)
+    want = ops.linear_bwd_input(dy, w, gelu_pre=pre)
+    want_cs = want.float().sum(0)
+    cs = torch.full((K,), 5.0, device=DEV)
+    got = ops.linear_bwd_input(dy, w, gelu_pre=pre, colsum_to=cs)                 # not deferred: fallback pass
+    assert torch.equal(got, want) and rel(cs, want_cs) < 1e-5
+    ops.enable_deferred_reductions(torch.device(DEV), workspace_mb=64)
+    try:
+        for _ in range(2):
+            cs = torch.full((K,), 5.0, device=DEV)
+            got = ops.linear_bwd_input(dy, w, gelu_pre=pre, colsum_to=cs)
+            ops.flush_reductions()
+            assert torch.equal(got, want) and rel(cs, want_cs) < 1e-5
+    finally:
+        ops.disable_deferred_reductions()
