@@ -27,8 +27,9 @@ template <typename T> __device__ __forceinline__ float to_f(T v) { return (float
 template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
 
 // Wave-wide (64-lane) all-reduce on the VALU: four DPP butterfly steps inside each 16-lane row (quad_perm x2,
-// row_half_mirror, row_mirror), then the four row results are combined through scalar registers (v_readlane).
-// ~12 VALU instructions; the ds_bpermute-based __shfl_xor ladder this replaces cost six dependent LDS round trips.
+// row_half_mirror, row_mirror), then the four rows through v_permlane16_swap / v_permlane32_swap (no scalar round trip:
+// the v_readlane form cost ~0.6 % of the step in the reduction-heavy loss kernels).  8 VALU instructions; the
+// ds_bpermute-based __shfl_xor ladder these replace cost six dependent LDS round trips.
 template <int CTRL>
 __device__ __forceinline__ float dvlp_dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
@@ -38,22 +39,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dvlp_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
     v += dvlp_dpp<0x141>(v);     // row_half_mirror
     v += dvlp_dpp<0x140>(v);     // row_mirror
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-    return (a + b) + (c + d);
+    // the four 16-lane rows: v_permlane16_swap / v_permlane32_swap of the value with itself (xor-16, xor-32 steps), all VALU
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dvlp_dpp<0xB1>(v));
     v = fmaxf(v, dvlp_dpp<0x4E>(v));
     v = fmaxf(v, dvlp_dpp<0x141>(v));
     v = fmaxf(v, dvlp_dpp<0x140>(v));
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 // all-reduce over the four lanes {c, c+16, c+32, c+48} that share lane&15 (the MFMA attention kernels' per-query
 // statistics in the "S^T" layout): v_permlane16_swap / v_permlane32_swap of a value with itself leave the pair's two
