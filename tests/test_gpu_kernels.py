@@ -224,7 +224,8 @@ def test_text_embed(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Bi,Bj,G,W,gate,general", [(2, 2, 288, 99, True, False), (3, 4, 240, 99, True, False), (2, 3, 30, 99, True, False),
                                                       (3, 3, 64, 17, False, False), (2, 2, 1152, 99, True, False),
-                                                      (2, 3, 288, 99, True, True), (3, 2, 30, 99, False, True)])
+                                                      (2, 3, 288, 99, True, True), (3, 2, 30, 99, False, True),
+                                                      (1, 3, 288, 99, True, False), (2, 1, 72, 99, True, False), (1, 1, 36, 8, True, False)])
 def test_xattn(dtype, Bi, Bj, G, W, gate, general):
     """general=True forces the long-video (general-G) softmax path on shapes the fused kernels also handle; G=1152 takes it
     by itself (the [G, W] tile no longer fits LDS)."""
@@ -454,3 +455,23 @@ def test_gemm_fused_column_sums(dtype, M, N, K):
             assert torch.equal(got, want) and rel(cs, want_cs) < 1e-5
     finally:
         ops.disable_deferred_reductions()
+
+
+def test_region_select_edge_counts():
+    """Frames with a single region, exactly R regions and more than R regions in one batch (ragged valid counts), against the
+    loader's numpy pipeline bit for bit."""
+    R, F = 30, 3
+    counts = [1, 30, 45]
+    frames = [syn.make_frame(40, f, n) for f, n in enumerate(counts)]
+    M = max(counts)
+    feats = torch.zeros(1, F, M, 2048); bbox = torch.zeros(1, F, M, 4); conf = torch.full((1, F, M), -1.0)
+    for f, fr in enumerate(frames):
+        n = counts[f]
+        feats[0, f, :n] = torch.from_numpy(fr["x"]); bbox[0, f, :n] = torch.from_numpy(fr["bbox"]); conf[0, f, :n] = torch.from_numpy(fr["objects_conf"])
+    wh = torch.tensor([[[640.0, 360.0]] * F])
+    nvalid = torch.tensor([counts], dtype=torch.int32)
+    obj, mask, order, lens = ops.region_select(feats.to(DEV), bbox.to(DEV), conf.to(DEV), wh.to(DEV), R, nvalid=nvalid.to(DEV))
+    want, wmask, wlens, _ = orc.region_select([fr["x"] for fr in frames], [fr["bbox"] for fr in frames], [fr["objects_conf"] for fr in frames], 640, 360, R)
+    assert lens[0].tolist() == wlens == [1, 30, 30]
+    assert np.array_equal(obj[0].cpu().numpy(), want) and np.array_equal(mask[0].cpu().numpy().astype(np.float64), wmask)
+
