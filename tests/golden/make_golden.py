@@ -224,12 +224,57 @@ def golden_xattn(ref_loss):
     print("g4 written")
 
 
+def golden_metrics(ref_loss):
+    """G7: the reference's retrieval metrics (model/metric.py:10-214) on similarity matrices with forced ties, and the eval-time
+    full-grid local similarity (RWALoss.get_sim_by_segment, model/loss.py:73-103; ragged last tiles: 11 videos x 22 captions,
+    two captions per video)."""
+    import importlib.util
+    import scipy.stats  # noqa: F401  (model/metric.py imports it lazily through numpy.ma on some versions)
+    spec = importlib.util.spec_from_file_location("refmetric", "/root/reference/model/metric.py")
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, (nq, nv) in {"sq64": (64, 64), "rect": (60, 20)}.items():
+        s = rng.standard_normal((nq, nv))
+        s[np.arange(nq), np.arange(nq) // (nq // nv)] += 1.5
+        s = np.round(s, 1)   # force ties
+        out[tag + "_sims"] = s
+        for name, fn in (("t2v", rm.t2v_metrics), ("v2t", rm.v2t_metrics)):
+            m = fn(s.copy())
+            out[f"{tag}_{name}"] = np.array([m[k] for k in keys], np.float64)
+    # eval grid: inputs re-derivable from the seed (tests/helpers.py:eval_grid_inputs)
+    nv, nt, G, W = 11, 22, 72, 99
+    rng = np.random.default_rng(77)
+    im = rng.standard_normal((nv, G, 256), dtype=np.float32)
+    cap = rng.standard_normal((nt, W, 256), dtype=np.float32)
+    for b in range(nt):
+        cap[b, :G, :64] += 0.5 * im[b // 2, :, :64]
+    m_img = np.zeros((nv, G), np.float32)
+    m_img[3, G - 6:] = -100.0
+    lens = rng.integers(5, 30, nt)
+    m_cap = np.full((nt, W), -100.0, np.float32)
+    for b in range(nt):
+        m_cap[b, : lens[b]] = 0.0
+    sims = ref_loss.RWALoss(20, "equal").get_sim_by_segment(torch.from_numpy(im), torch.from_numpy(cap), torch.from_numpy(m_img),
+                                                          torch.from_numpy(lens), torch.from_numpy(m_cap), segment=8, device="cpu")
+    out["grid_sims"] = sims
+    out["grid_lens"] = lens
+    for name, fn in (("t2v", rm.t2v_metrics), ("v2t", rm.v2t_metrics)):
+        m = fn(sims.T.copy())                                          # metrics take [n_text, n_video] (trainer_dist.py:370-399)
+        out[f"grid_{name}"] = np.array([m[k] for k in keys], np.float64)
+    np.savez_compressed(os.path.join(HERE, "g7_metrics.npz"), **out)
+    print("g7 written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_model, ref_loss, ref_data, scratch = import_reference()
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
+    golden_metrics(ref_loss)
     golden_model(ref_model, ref_loss, ref_data, scratch, F=8, R=36, B=2, tag="F8_R36_B2")
     golden_model(ref_model, ref_loss, ref_data, scratch, F=8, R=30, B=3, tag="F8_R30_B3")
     golden_model(ref_model, ref_loss, ref_data, scratch, F=1, R=30, B=4, tag="F1_R30_B4")

@@ -40,3 +40,21 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def eval_grid_inputs():
+    """Inputs of the G7 eval-grid golden (tests/golden/make_golden.py:golden_metrics): 11 videos x 22 captions, G=72, W=99."""
+    nv, nt, G, W = 11, 22, 72, 99
+    rng = np.random.default_rng(77)
+    im = rng.standard_normal((nv, G, 256), dtype=np.float32)
+    cap = rng.standard_normal((nt, W, 256), dtype=np.float32)
+    for b in range(nt):
+        cap[b, :G, :64] += 0.5 * im[b // 2, :, :64]
+    m_img = np.zeros((nv, G), np.float32)
+    m_img[3, G - 6:] = -100.0
+    lens = rng.integers(5, 30, nt)
+    m_cap = np.full((nt, W), -100.0, np.float32)
+    for b in range(nt):
+        m_cap[b, : lens[b]] = 0.0
+    return im, cap, m_img, lens, m_cap
+

@@ -260,3 +260,21 @@ def test_two_rank_data_parallel_step_matches_averaged_gradients(overlap):
         assert abs(l0[step] - ref_losses[step][0]) < 1e-5 * max(1.0, abs(l0[step])) and abs(l1[step] - ref_losses[step][1]) < 1e-5 * max(1.0, abs(l1[step]))
     pref = arena.flat_p[::9973].double().cpu().numpy()
     assert np.abs(p0 - pref).max() <= 1e-5 * max(1.0, np.abs(pref).max())
+
+
+def test_eval_grid_and_retrieval_metrics_vs_reference_golden():
+    """Eval path: RWALoss.get_sim_by_segment on the device over a ragged 11 x 22 grid against the
+    reference's tiled loop, then R@K / MedR / MeanR from that matrix against the reference's metrics (golden G7)."""
+    from demovlp_amd import metric
+    from demovlp_amd.loss import RWALoss
+    from helpers import eval_grid_inputs
+    g = load_golden("g7_metrics.npz")
+    im, cap, m_img, lens, m_cap = eval_grid_inputs()
+    sims = RWALoss(20, "equal").get_sim_by_segment(torch.from_numpy(im), torch.from_numpy(cap), torch.from_numpy(m_img),
+                                                   torch.from_numpy(lens), torch.from_numpy(m_cap), segment=8, device="cuda")
+    assert sims.shape == (11, 22) and rel_err(sims, g["grid_sims"]) < 1e-4
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
+        got = fn(sims.T.copy())
+        assert np.allclose([got[k] for k in keys], g[f"grid_{name}"], rtol=1e-9, atol=1e-9), name
+

@@ -113,3 +113,15 @@ def test_model_forward_backward(tag, with_grads):
             ref = g[k]
             got = p[name].grad.numpy().reshape(-1)[idx]
             assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), name
+
+
+def test_eval_grid_scores_match_reference_get_sim_by_segment():
+    """The oracle's batched local similarity over a ragged video x caption grid == the reference's 8 x 8-tiled
+    RWALoss.get_sim_by_segment (golden G7)."""
+    from helpers import eval_grid_inputs
+    g = load_golden("g7_metrics.npz")
+    im, cap, m_img, lens, m_cap = eval_grid_inputs()
+    assert np.array_equal(lens, g["grid_lens"])
+    got = orc.xattn_scores_batched(torch.from_numpy(im), torch.from_numpy(cap), torch.from_numpy(m_img), torch.from_numpy(m_cap), 20.0, True)
+    assert rel_err(got.numpy(), g["grid_sims"]) < 1e-4
+
