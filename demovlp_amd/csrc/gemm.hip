@@ -115,7 +115,7 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
     bf16x8 o;
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
-    *(bf16x8*)Cp = o;
+    __builtin_nontemporal_store(o, (bf16x8*)Cp);      // streaming: keep the operand panels in L2 (see epi_store8_pre)
 }
 
 // epi_store8 for a whole, aligned 8-column group with the operands it would load (bias, residual, aux-in) already in
@@ -129,7 +129,7 @@ __device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ 
         bf16x8 pre;
 #pragma unroll
         for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_fast(v[t]); }
-        *(bf16x8*)((bf16*)e.aux + m * e.ldaux + n) = pre;
+        __builtin_nontemporal_store(pre, (bf16x8*)((bf16*)e.aux + m * e.ldaux + n));
     }
     if (e.flags & EPI_LEAKY) {
 #pragma unroll
@@ -166,7 +166,9 @@ __device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ 
     bf16x8 o;
 #pragma unroll
     for (int t = 0; t < 8; ++t) { o[t] = (bf16)v[t]; v[t] = (float)o[t]; }     // v <- the values as stored (column-sum fusion)
-    *(bf16x8*)Cp = o;
+    // streaming store: a 256 x 256 tile's outputs (128-256 KB per CU per round) would otherwise push the operand panels that the
+    // neighbouring column tiles are about to re-read out of the 4 MiB L2
+    __builtin_nontemporal_store(o, (bf16x8*)Cp);
 }
 
 // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of tiles
