@@ -1,0 +1,134 @@
+// Shared device helpers for the DemoVLP gfx950 kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { DVLP_F32 = 0, DVLP_BF16 = 1 };
+enum { DVLP_OK = 0, DVLP_ERR_DTYPE = -1, DVLP_ERR_SHAPE = -2, DVLP_ERR_LAUNCH = -3, DVLP_ERR_UNSUPPORTED = -4 };
+
+// epilogue flags of dvlp_gemm (keep in sync with include/demovlp_hip.h)
+enum {
+    EPI_GELU = 1,       // aux <- pre-activation, C <- gelu_erf(v)
+    EPI_GELU_BWD = 2,   // v *= gelu'(aux)
+    EPI_RELU_BWD = 4,   // v = aux > 0 ? v : 0
+    EPI_ACCUM = 8,      // C += v
+    EPI_OUT_F32 = 32,   // C is float* regardless of the compute dtype (weight gradients go straight to fp32)
+    EPI_LEAKY = 16,     // v = v > 0 ? v : 0.1 v   (LeakyReLU(0.1), model/loss.py:236)
+};
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+// Wave-wide (64-lane) all-reduce on the VALU: four DPP butterfly steps inside each 16-lane row (quad_perm x2,
+// row_half_mirror, row_mirror), then the four rows through v_permlane16_swap / v_permlane32_swap (no scalar round trip:
+// the v_readlane form cost ~0.6 % of the step in the reduction-heavy loss kernels).  8 VALU instructions; the
+// ds_bpermute-based __shfl_xor ladder these replace cost six dependent LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ float dvlp_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dvlp_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dvlp_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dvlp_dpp<0x141>(v);     // row_half_mirror
+    v += dvlp_dpp<0x140>(v);     // row_mirror
+    // the four 16-lane rows: v_permlane16_swap / v_permlane32_swap of the value with itself (xor-16, xor-32 steps), all VALU
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dvlp_dpp<0xB1>(v));
+    v = fmaxf(v, dvlp_dpp<0x4E>(v));
+    v = fmaxf(v, dvlp_dpp<0x141>(v));
+    v = fmaxf(v, dvlp_dpp<0x140>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+// all-reduce over the four lanes {c, c+16, c+32, c+48} that share lane&15 (the MFMA attention kernels' per-query
+// statistics in the "S^T" layout): v_permlane16_swap / v_permlane32_swap of a value with itself leave the pair's two
+// members in the two results, so one swap + one add is an xor-16 (xor-32) all-reduce step.
+__device__ __forceinline__ float col4_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float col4_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+// all-reduce inside each aligned group of 8 lanes (a 64-channel row read as 8 lanes x 8 channels)
+__device__ __forceinline__ float oct_sum(float v) {
+    v += dvlp_dpp<0xB1>(v); v += dvlp_dpp<0x4E>(v); v += dvlp_dpp<0x141>(v);
+    return v;
+}
+// all-reduce over the eight lanes {c, c+8, ..., c+56} that share lane&7: row_ror:8 is the xor-8 step inside a 16-lane row
+__device__ __forceinline__ float stride8_sum(float v) {
+    v += dvlp_dpp<0x128>(v);
+    return col4_sum(v);
+}
+// all-reduce inside each 16-lane row only (the MFMA attention kernels' per-query statistics in the "S" layout)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dvlp_dpp<0xB1>(v); v += dvlp_dpp<0x4E>(v); v += dvlp_dpp<0x141>(v); v += dvlp_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dvlp_dpp<0xB1>(v)); v = fmaxf(v, dvlp_dpp<0x4E>(v)); v = fmaxf(v, dvlp_dpp<0x141>(v)); v = fmaxf(v, dvlp_dpp<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// bf16 epilogues: GELU through the Abramowitz-Stegun 7.1.26 rational form of erf (|error| <= 1.5e-7 absolute, two orders
+// below bf16 resolution): ONE v_exp_f32 shared by the erf tail and the Gaussian of the derivative, one v_rcp_f32, ~10 FMAs.
+// The libm erff/expf pair these replace cost ~100 VALU instructions per element and made the fc1 backward GEMM (57 M
+// outputs per layer) spend as long in its epilogue as in its MFMAs.  The fp32 kernels keep erff/expf (1e-4 parity path).
+__device__ __forceinline__ void gelu_fast_parts(float x, float& Phi, float& E) {
+    const float ax = fabsf(x);
+    E = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);                 // exp(-x^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189867f, ax, 1.0f));      // 1 / (1 + p |x| / sqrt(2)), p = 0.3275911
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float q = 0.5f * poly * t * E;                                          // upper tail 1 - Phi(|x|)
+    Phi = x >= 0.f ? 1.0f - q : q;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float Phi, E;
+    gelu_fast_parts(x, Phi, E);
+    return x * Phi;
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+    float Phi, E;
+    gelu_fast_parts(x, Phi, E);
+    return fmaf(x * 0.39894228040143267794f, E, Phi);
+}
+
+// hipGetLastError() is sticky per thread and also reports errors left behind by OTHER libraries' benign failed calls
+// (e.g. a failed attribute query inside the framework), so judge a launch by the error state it changes: clear before
+// launching (dvlp_clear_status) and read after (dvlp_launch_status).
+extern int g_dvlp_last_hip_error;      // defined in gemm.hip; read through dvlp_last_error_string()
+static inline void dvlp_clear_status() { (void)hipGetLastError(); }
+static inline int dvlp_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return DVLP_OK;
+    g_dvlp_last_hip_error = (int)e;
+    return DVLP_ERR_LAUNCH;
+}
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

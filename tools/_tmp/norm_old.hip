@@ -52,28 +52,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int64_t M, int NC, const T*
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma ;  partial dgamma/dbeta per block.
-template <typename T, int CS, int NCT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t M, int NC_, const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t M, int NC, const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres, T* __restrict__ dx,
-                                                     float* __restrict__ partial /* [grid][2 + CS][D] */) {
-    constexpr int cs = CS;      // compile-time: a run-time test inside the row loop cost the kernel ~15 %
-    constexpr int NC = NCT;     // compile-time too: sized for D = 1024 the per-lane arrays pushed the CS variant past 128 VGPRs
-    (void)NC_;                  // (3 waves per SIMD instead of 4: its 1024 workgroups then needed a second round)
-    // cs: also emit the column sums of the OUTPUT dx (third plane): dx feeds a Linear whose bias gradient is exactly that sum,
-    // which saves a separate pass over dx (values are summed as stored, i.e. after rounding to T, like that pass would)
-    extern __shared__ __attribute__((aligned(16))) float red_[];      // [4 waves][2 + cs planes][D]
+                                                     float* __restrict__ partial /* [grid][2][D] */) {
+    __shared__ float red[4][2][LN_MAXC * 256];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int D = NC * 256;
-    float dg[NCT][4], db[NCT][4], gm[NCT][4], dc[NCT][4];
+    float dg[LN_MAXC][4], db[LN_MAXC][4], gm[LN_MAXC][4];
     for (int c = 0; c < NC; ++c) {
         Vec4<float>::load(gamma + c * 256 + lane * 4, gm[c]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; dc[c][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < M; row += (int64_t)gridDim.x * 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
-        float xh[NCT][4], g[NCT][4];
+        float xh[LN_MAXC][4], g[LN_MAXC][4];
         float s1 = 0.f, s2 = 0.f;
         for (int c = 0; c < NC; ++c) {
             float d[4];
@@ -102,23 +97,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t M, int NC_, const T
                 for (int j = 0; j < 4; ++j) o[j] += r[j];
             }
             Vec4<T>::store(dx + row * D + c * 256 + lane * 4, o);
-            if (cs) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dc[c][j] += to_f(from_f<T>(o[j]));
-            }
         }
     }
-    const int planes = 2 + (cs ? 1 : 0);
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = c * 256 + lane * 4 + j;
-            red_[(wid * planes + 0) * D + col] = dg[c][j]; red_[(wid * planes + 1) * D + col] = db[c][j];
-            if (cs) red_[(wid * planes + 2) * D + col] = dc[c][j];
-        }
+        for (int j = 0; j < 4; ++j) { red[wid][0][c * 256 + lane * 4 + j] = dg[c][j]; red[wid][1][c * 256 + lane * 4 + j] = db[c][j]; }
     __syncthreads();
-    for (int i = threadIdx.x; i < planes * D; i += 256)
-        partial[(int64_t)blockIdx.x * planes * D + i] = red_[i] + red_[planes * D + i] + red_[2 * planes * D + i] + red_[3 * planes * D + i];
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int w = i / D, col = i % D;
+        partial[(int64_t)blockIdx.x * 2 * D + i] = red[0][w][col] + red[1][w][col] + red[2][w][col] + red[3][w][col];
+    }
 }
 
 // out[g][c] (+)= sum_p in[(g*P + p)*C + c].  32 columns x 8 partial-sum lanes per workgroup: the P-loop is split
@@ -265,14 +253,6 @@ static void rd_push(const float* in, float* out, int64_t P, int64_t C, int64_t s
     g_rd.nblk += (int)cdiv(C, 32);
 }
 
-// used by the GEMM's fused column sums (gemm.hip): reserve partial space / queue a reduction under the queue's lock
-float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out) {
-    std::lock_guard<std::mutex> lk(g_rd.mu);
-    float* p = rd_reserve(P * C, 1);
-    if (p) rd_push(p, out, P, C, C, 0);
-    return p;
-}
-
 __global__ __launch_bounds__(256) void reduce_batched_kernel(const RItem* __restrict__ items, int nitems) {
     __shared__ float red[8][33];
     // which item owns this block: binary search over the items' first-block prefix (<= ~10 steps, wave-uniform)
@@ -322,39 +302,24 @@ extern "C" int dvlp_reduce_flush(void* stream) {
 // workspace: fp32 [(dvlp_layernorm_bwd_blocks(M) + 1) * 2 * D].  dgamma/dbeta are overwritten (accumulate=0) or added to.
 extern "C" int64_t dvlp_layernorm_bwd_blocks(int64_t M) { const int64_t b = cdiv(M, 4); return b < 1024 ? b : 1024; }
 
-extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
-                           int64_t gstride, float* out, float* workspace, int accumulate, void* stream);
-
 extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace,
-                                  int accumulate, float* dx_colsum, void* stream) {
+                                  int accumulate, void* stream) {
     dvlp_clear_status();
     if (D % 256 || D > 256 * LN_MAXC || M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = dvlp_layernorm_bwd_blocks(M);
     dim3 grid((unsigned)nb), block(256);
     std::unique_lock<std::mutex> lk(g_rd.mu);
-    // dx_colsum (the bias gradient of the Linear that dx feeds) rides along only on the deferred path: a third partial plane
-    const int cs = (dx_colsum && (accumulate & 2)) ? 1 : 0;
-    float* dws = (accumulate & 2) ? rd_reserve(nb * (2 + cs) * D, 2 + cs) : nullptr;
-    const int csk = dws ? cs : 0;
+    float* dws = (accumulate & 2) ? rd_reserve(nb * 2 * D, 2) : nullptr;
     if (dws) workspace = dws;
-    const size_t ldsb = (size_t)4 * (2 + csk) * D * sizeof(float);
-#define LNB_(T_, CS_, NC_) hipLaunchKernelGGL((ln_bwd_kernel<T_, CS_, NC_>), grid, block, ldsb, st, M, NC_, (const T_*)dy, (const T_*)x, gamma, mean, rstd, \
-                                              (const T_*)dres, (T_*)dx, workspace)
-#define LNB(T_, CS_) do { switch ((int)(D / 256)) { case 1: LNB_(T_, CS_, 1); break; case 2: LNB_(T_, CS_, 2); break; case 3: LNB_(T_, CS_, 3); break; \
-                                                    default: LNB_(T_, CS_, 4); break; } } while (0)
-    if (dtype == DVLP_F32) { if (csk) LNB(float, 1); else LNB(float, 0); }
-    else if (dtype == DVLP_BF16) { if (csk) LNB(bf16, 1); else LNB(bf16, 0); }
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, M, (int)(D / 256), (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, workspace);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, st, M, (int)(D / 256), (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, workspace);
     else return DVLP_ERR_DTYPE;
-#undef LNB
-#undef LNB_
-    // partial layout [nb][2 (+1)][D]: reduce the planes separately (stride = planes * D between blocks)
+    // partial layout [nb][2][D]: reduce the two halves separately (stride 2D between blocks)
     if (dws) {
-        const int64_t pl = (2 + csk) * D;
-        if (dbeta == dgamma + D) rd_push(dws, dgamma, nb, 2 * D, pl, accumulate & 1);
-        else { rd_push(dws, dgamma, nb, D, pl, accumulate & 1); rd_push(dws + D, dbeta, nb, D, pl, accumulate & 1); }
-        if (csk) rd_push(dws + 2 * D, dx_colsum, nb, D, pl, 0);
+        if (dbeta == dgamma + D) rd_push(dws, dgamma, nb, 2 * D, 2 * D, accumulate & 1);
+        else { rd_push(dws, dgamma, nb, D, 2 * D, accumulate & 1); rd_push(dws + D, dbeta, nb, D, 2 * D, accumulate & 1); }
         return dvlp_launch_status();
     }
     lk.unlock();
@@ -366,10 +331,7 @@ extern "C" int dvlp_layernorm_bwd(int dtype, int64_t M, int64_t D, const void* d
         hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(D, 32), 1), dim3(256), 0, st, (int64_t)1, D, workspace + nb * 2 * D, dgamma, accumulate);
         hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv(D, 32), 1), dim3(256), 0, st, (int64_t)1, D, workspace + nb * 2 * D + D, dbeta, accumulate);
     }
-    if (int rc = dvlp_launch_status()) return rc;
-    // not deferred: the column sums of dx are a plain second pass (the LayerNorm workspace is free again in stream order)
-    if (dx_colsum) return dvlp_colsum(dtype, M, D, dx, D, M, 0, 1, 0, dx_colsum, workspace, 0, stream);
-    return DVLP_OK;
+    return dvlp_launch_status();
 }
 
 // out[g][n] (+)= sum_m x_g[m][n]   (bias / embedding-table gradients).  Row m of group g is at
