@@ -741,8 +741,10 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 //            operand, K is read with the transposing read.  Per-frame partials of the shared CLS key go to `ws` as before;
 //   launch C (attn_bwd_cls_post_kernel): sums those partials into dK / dV of the CLS key.
 // ------------------------------------------------------------------------------------------------------------------
+// (two waves per SIMD: left alone the compiler takes 328 VGPRs for NT = 3 -- one wave per SIMD, 102 us per layer; capped at 256 it
+//  spills 16 and runs in 80 us; three waves per SIMD would spill 101 and take 129 us)
 template <int NT>
-__global__ __launch_bounds__(256) void mattn_bwd_space_merged_kernel(AttnArgs a, int items, const float* __restrict__ stats) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mattn_bwd_space_merged_kernel(AttnArgs a, int items, const float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     constexpr int NTP = (NT + 1) & ~1, TROWS = 16 * NTP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
