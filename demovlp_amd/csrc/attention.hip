@@ -741,8 +741,9 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 //            operand, K is read with the transposing read.  Per-frame partials of the shared CLS key go to `ws` as before;
 //   launch C (attn_bwd_cls_post_kernel): sums those partials into dK / dV of the CLS key.
 // ------------------------------------------------------------------------------------------------------------------
-// (two waves per SIMD: left alone the compiler takes 328 VGPRs for NT = 3 -- one wave per SIMD, 102 us per layer; capped at 256 it
-//  spills 16 and runs in 80 us; three waves per SIMD would spill 101 and take 129 us)
+// (two waves per SIMD: left alone the compiler takes 328 VGPRs for NT = 3 -- one wave per SIMD, 102 us per layer.  With Q and K
+//  re-read for the second / third stage instead of held in registers it fits 244 without spilling: 80 us.  Three waves per SIMD
+//  would spill ~100 registers and take 129 us.)
 template <int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mattn_bwd_space_merged_kernel(AttnArgs a, int items, const float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
@@ -810,7 +811,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     // dV[key][d] = sum_q P[q][key] dO[q][d];  dK[key][d] = scale * sum_q dS[q][key] Q[q][d]
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 0) put_row_frags<NT, NTP>(Ts, gf, lane); else put_row_frags<NT, NTP>(Ts, qf, lane);
+        if (pass == 0) put_row_frags<NT, NTP>(Ts, gf, lane);
+        else {      // Q again from global (L2-warm): keeping its fragments alive across pass 0 costs 24 VGPRs at the kernel's peak
+            bf16x8 q2[NT][2];
+            load_row_frags<NT>(q2, q, brow0, a.ld, h, sg, false, lane);
+            put_row_frags<NT, NTP>(Ts, q2, lane);
+        }
         f32x4 acc[NT][4];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -844,7 +850,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         emit_rows<NT>(Ts, acc, mul, dst, brow0, a.ldd, h, sg, true, lane);
     }
     // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: K through the tile (transposing read, natural key order), then dS
-    put_row_frags<NT, NTP>(Ts, kf, lane);
+    {               // K again from global (L2-warm), for the same reason
+        bf16x8 k2[NT][2];
+        load_row_frags<NT>(k2, k, brow0, a.ld, h, sg, true, lane);
+        put_row_frags<NT, NTP>(Ts, k2, lane);
+    }
     bf16x8 kb[NTP / 2][4];
 #pragma unroll
     for (int ks = 0; ks < NTP / 2; ++ks)
