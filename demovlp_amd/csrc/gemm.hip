@@ -17,6 +17,7 @@
 #include "common.h"
 #include <vector>
 #include <cstdlib>
+#include <cstdlib>
 
 struct Epi {
     const float* bias;   // [N] fp32 or null
@@ -1328,9 +1329,10 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         const int64_t ntm8 = cdiv(M, 256), ntn8 = cdiv(N, 256), tiles8 = ntm8 * ntn8 * batch;
         // ... and outputs that fill its tiles: 288 columns would leave the second 256-wide tile 7/8 empty
         const bool fills8 = 10 * M * N >= 8 * (ntm8 * 256) * (ntn8 * 256);
-        // ... and a tile count that fills whole rounds of the 256 CUs (300 tiles = 2 rounds for 1.17 rounds of work)
+        // ... and a tile count that fills whole rounds of the 256 CUs (300 tiles = 2 rounds for 1.17 rounds of work); a long K
+        // (>= 32 K tiles) amortises its fixed costs well enough to win even at 75 tiles
         const bool rounds8 = 10 * tiles8 >= 8 * 256 * cdiv(tiles8, 256);
-        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 <= 64 && K >= 4096))));
+        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 <= 64 && K >= 4096) || (tiles8 >= 64 && tiles8 < 192 && K >= 2048))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
         // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32
         // slabs (deterministic, no float atomics).
