@@ -42,7 +42,8 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int B = a.B, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float* nt = sm; float* no = nt + B; float* lse_r = no + B; float* lse_c = lse_r + B; float* red = lse_c + B;
-    float* E = red + 32;                      // staged: [2B][256] fp32 copies of gt (rows 0..B-1) and go (rows B..2B-1)
+    float* rnt = red + 32; float* rno = rnt + B;          // reciprocal norms (the loops below would otherwise divide per entry)
+    float* E = rno + B;                       // staged: [2B][256] fp32 copies of gt (rows 0..B-1) and go (rows B..2B-1)
     const T* gt = (const T*)a.gt; const T* go = (const T*)a.go;
     // row r of the stacked (gt | go) matrix, 4 channels per lane: from LDS when staged -- this is a ONE-workgroup kernel, so
     // every row re-read from global memory inside the B x B loops below was a full, unhidden memory round trip
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
             l4<T>((r < B ? gt + (int64_t)r * LD_ : go + (int64_t)(r - B) * LD_) + lane * 4, v);
             if (a.staged) *(float4*)&E[r * LD_ + lane * 4] = make_float4(v[0], v[1], v[2], v[3]);
             const float n = sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
-            if (lane == 0) (r < B ? nt[r] : no[r - B]) = fmaxf(n, 1e-8f);
+            if (lane == 0) { (r < B ? nt[r] : no[r - B]) = fmaxf(n, 1e-8f); (r < B ? rnt[r] : rno[r - B]) = 1.f / fmaxf(n, 1e-8f); }
         }
         __syncthreads();
     }
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
             ldrow(t, x); ldrow(B + o, y);
             float d = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d += (x[c] / nt[t]) * (y[c] / no[o]);
-            d = wave_sum(d);
+            for (int c = 0; c < 4; ++c) d += x[c] * y[c];
+            d = wave_sum(d) * (rnt[t] * rno[o]);
             if (lane == 0) a.sim[e] = d;
         }
         __syncthreads();
@@ -102,12 +103,17 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
     }
     if (a.use_global && (a.stages & 4)) {
         // d/d normalised rows, then through a / max(|a|, eps)
+        float* Ds = E + 2 * B * LD_;                 // staged: dsim [B][B] (the row loop below re-read it from global memory entry by entry)
+        if (a.staged) {
+            for (int e = threadIdx.x; e < B * B; e += blockDim.x) Ds[e] = a.dsim[e];
+            __syncthreads();
+        }
         for (int r = wid; r < 2 * B; r += nw) {
             const bool row = r < B; const int idx = row ? r : r - B;
-            const float* on = row ? no : nt;
+            const float* ron = row ? rno : rnt;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < B; ++k) {
-                const float w = (row ? a.dsim[idx * B + k] : a.dsim[k * B + idx]) / on[k];
+                const float w = (a.staged ? (row ? Ds[idx * B + k] : Ds[k * B + idx]) : (row ? a.dsim[idx * B + k] : a.dsim[k * B + idx])) * ron[k];
                 float y[4];
                 ldrow(row ? B + k : k, y);
 #pragma unroll
@@ -165,7 +171,7 @@ extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const voi
     if (use_local && !xs) return DVLP_ERR_SHAPE;
     const int staged = B <= 64 ? 1 : 0;
     LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages, staged};
-    const size_t lds = (size_t)(4 * B + 32 + (staged ? 2 * B * LD_ : 0)) * sizeof(float);
+    const size_t lds = (size_t)(6 * B + 32 + (staged ? 2 * B * LD_ + B * B : 0)) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     { static bool once = false; if (!once) { once = true;
         (void)hipFuncSetAttribute((const void*)loss_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
