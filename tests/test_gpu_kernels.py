@@ -352,7 +352,9 @@ def test_gemm_pingpong_race_screen(form):
 
 def test_deferred_reductions_match_immediate():
     """Column sums / LayerNorm parameter gradients whose final reduction is queued and run as one batched launch
-    (ops.flush_reductions) equal the immediately reduced ones bit for bit; the queue table is reused across 'steps'."""
+    (ops.flush_reductions) equal the immediately reduced ones (same partial sums, a different fp32 summation order: 1e-6);
+    the queue table is reused across 'steps'."""
+    same = lambda a_, b_: rel(a_, b_) < 1e-6          # noqa: E731
     torch.manual_seed(0)
     xs = [rnd(1000, 768, dtype=torch.bfloat16), rnd(18496, 3072, dtype=torch.bfloat16, seed=3), rnd(300, 2304, dtype=torch.bfloat16, seed=4)]
     M, D = 4000, 768
@@ -377,11 +379,11 @@ def test_deferred_reductions_match_immediate():
             assert float(outs[0][0]) == 7.0                      # really deferred: nothing written yet
             ops.flush_reductions()
             for o, w in zip(outs, want_cs):
-                assert torch.equal(o, w)
-            assert torch.equal(gb[:D], dg0) and torch.equal(gb[D:], db0)
-            assert torch.equal(split_g, dg0) and torch.equal(split_b, db0)
+                assert same(o, w)
+            assert same(gb[:D], dg0) and same(gb[D:], db0)
+            assert same(split_g, dg0) and same(split_b, db0)
             assert torch.equal(dx1, dx0) and torch.equal(dx2, dx0) and torch.equal(dx3, dx0)
-            assert torch.equal(g3[:D], dg0) and torch.equal(g3[D:], db0)
+            assert same(g3[:D], dg0) and same(g3[D:], db0)
             assert rel(cs, dx0.float().sum(0)) < 1e-5
     finally:
         ops.disable_deferred_reductions()
