@@ -362,15 +362,19 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
         for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + hl + 32 * k] = cd[k];
     }
     __syncthreads();
+    // rowdot / coldot hold the finished correction factors <dA,S> r^2 / (1/r - eps): computed once per row / column here instead of
+    // once per element in the last pass (two divisions per element of the 288 x 99 tile)
     for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
         float t = 0.f;
         for (int k = 0; k < nw; ++k) t += rpart[k * a.G + g];
-        rowdot[g] = t;
+        const float r = rn[g];
+        rowdot[g] = t * r * r / fmaxf(1.f / r - 1e-8f, 1e-30f);
     }
     for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
         float t = 0.f;
         for (int k = 0; k < 2 * nw; ++k) t += qpart[k * 32 * NKW + w];
-        coldot[w] = t;
+        const float c = cn[w];
+        coldot[w] = t * c * c / fmaxf(1.f / c - 1e-8f, 1e-30f);
     }
     __syncthreads();
     // A = S r with r = 1 / (|S_row| + eps):  dS = dA r - S <dA,S>_row r^2 / (1/r - eps); same along columns; then LeakyReLU'.
@@ -384,10 +388,10 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
         __syncthreads();
         for (int gl = wid; gl < ng; gl += nw) {
             const int g = g0 + gl;
-            const float r = rn[g], cr = rowdot[g] * r * r / fmaxf(1.f / r - 1e-8f, 1e-30f);
+            const float cr = rowdot[g];
             T* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
             for (int w = lane; w < a.W; w += 64) {
-                const float c = cn[w], cc = coldot[w] * c * c / fmaxf(1.f / c - 1e-8f, 1e-30f);
+                const float cc = coldot[w];
                 const float sv = Ssm[g * a.Wq + w];
                 const float ds = tile[gl * a.Wq + w] + to_f(D2[(int64_t)g * a.Wp + w]) - sv * (cr + cc);
                 row[w] = from_f<T>(sv > 0.f ? ds : 0.1f * ds);
