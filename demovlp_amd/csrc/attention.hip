@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kt][qt][r] = expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
+            for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
         sum = col4_sum(sum);
         const float inv = 1.f / sum;
 #pragma unroll
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[kt][qt][r] = expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
+                for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
             sum = col4_sum(sum);
             const float inv = 1.f / sum;
             float D = 0.f;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
                 m = row16_max(m);
                 float sum = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = (a.abl & 2) ? s2[qt][kt][r] - m : expf(s2[qt][kt][r] - m); sum += s2[qt][kt][r]; }
+                for (int kt = 0; kt < NKT; ++kt) { s2[qt][kt][r] = (a.abl & 2) ? s2[qt][kt][r] - m : __expf(s2[qt][kt][r] - m); sum += s2[qt][kt][r]; }
                 sum = row16_sum(sum);
                 const float inv = qok ? 1.f / sum : 0.f;                    // padded query rows contribute nothing
                 float D = 0.f;
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                float e = expf(s2[qt][kt][r] - m);
+                float e = __expf(s2[qt][kt][r] - m);
                 if (is_cls && kt == 0 && c == 0 && sg.f != 0) e = 0.f;    // CLS query x CLS key: counted once, in frame 0
                 s2[qt][kt][r] = e; sum += e;
             }
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kt][r] = expf(st[kt][r] - m); sum += st[kt][r]; }
+            for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); sum += st[kt][r]; }
         sum = col4_sum(sum);
         const float inv = 1.f / sum;
         float D = 0.f;
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
                 const int qi = 16 * qt + 4 * g + r;
                 const bool qok = sg.tok_q(qi) >= 0;
                 const float* sp = stats + qi * 3;
-                const float p = qok ? expf(s2[qt][r] * a.scale + mk - sp[0]) * sp[1] : 0.f;
+                const float p = qok ? __expf(s2[qt][r] * a.scale + mk - sp[0]) * sp[1] : 0.f;
                 s2[qt][r] = p;                                   // P[q][key]
                 dp[qt][r] = p * (dp[qt][r] - sp[2]);             // dS[q][key]
             }
