@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Throughput of the DemoVLP cross-modal hot path on MI355X: video-text pairs/s, fwd + bwd + optimizer step.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: starts its own N ranks)
 
 A step = trainer/trainer_dist.py:144-171 on one synthetic batch already resident in HBM: ObjectRelation forward (region
 transformer + DistilBERT), sim_matrix, GlobalLocalLoss (NT-Xent-style global + region<->word local loss, focal gate
@@ -18,11 +18,10 @@ the host cores, on a bounded sample.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -30,6 +29,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+TRAFFIC_FILES = ("r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
 
 
 def flops_per_pair(B, F, R, W=99, Lt=100):
@@ -55,13 +55,21 @@ def usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(F, R, budget_s=20.0):
-    """The oracle's full train step (fwd + loss + bwd) on the host cores at B=2 (BASELINE.json configs[0])."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _cpu_leg(B, F, R, budget_s, max_steps):
+    """oracle.train_step (fwd + loss + bwd, fp32, torch CPU) at per-step batch B: (pairs/s, description)."""
+    import torch
     from demovlp_amd import synthetic as syn
     from oracle import restatement as orc
-    B = 2
-    cores = usable_cores()
-    torch.set_num_threads(cores)
     p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=True)
     obj, mask = syn.fast_region_batch(B, F, R)
     ids, att = syn.caption_batch(B)
@@ -70,8 +78,7 @@ def cpu_baseline(F, R, budget_s=20.0):
     orc.train_step(p, *args)                                   # warm-up
     tw = time.perf_counter() - tw
     if tw > budget_s:                                          # a single step already exhausts the budget: report it
-        return dict(value=round(B / tw, 4), unit="pairs/s", cores=cores, kind="port",
-                    sample=f"1 step (the warm-up itself, {tw:.1f} s) of oracle.train_step at B={B}, F={F}, R={R}")
+        return B / tw, f"B={B}: 1 step (the warm-up itself, {tw:.1f} s)"
     n, t0 = 0, time.perf_counter()
     while True:
         for v in p.values():
@@ -79,10 +86,61 @@ def cpu_baseline(F, R, budget_s=20.0):
         orc.train_step(p, *args)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 8:
+        if dt + dt / n > budget_s or n >= max_steps:
             break
-    return dict(value=round(B * n / dt, 3), unit="pairs/s", cores=cores, kind="port",
-                sample=f"{n} steps of oracle.train_step (fwd+loss+bwd, fp32, torch CPU) at B={B}, F={F}, R={R}, after 1 warm-up")
+    return B * n / dt, f"B={B}: {n} steps after 1 warm-up ({dt:.1f} s)"
+
+
+def cpu_baseline(F, R):
+    """The oracle's full train step on the host cores at B=2 (BASELINE.json configs[0]) and B=16,
+    about 10 s of CPU work each.  ``value`` is the better of the two rates."""
+    import torch
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    v2, d2 = _cpu_leg(2, F, R, 8.0, 6)
+    v16, d16 = _cpu_leg(16, F, R, 12.0, 2)
+    return dict(value=round(max(v2, v16), 3), unit="pairs/s", cores=cores, kind="port", cpu=cpu_model_name(),
+                pairs_per_s_b2=round(v2, 3), pairs_per_s_b16=round(v16, 3),
+                sample=f"oracle.train_step (fwd+loss+bwd, fp32, torch CPU, {cores} threads) at F={F}, R={R}; {d2}; {d16}")
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh child ranks (one per GPU, RCCL rendezvous on
+    127.0.0.1) exactly as the driver's multi-GPU command would, relay their output, exit with their code.  The parent never
+    touches the GPU (train_dist_multi.py:33-38, 159-164 is the launch contract this mirrors)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def time_object_tower(model, data, steps, dist_sync):
+    """ObjectTransformer alone, forward + backward (weight gradients included, no optimizer): seconds per pass.  This is the
+    quantity BASELINE.json's north_star prices at >= 40 % of the bf16 MFMA peak (151.55 GFLOP per pair at F=8, R=36)."""
+    import torch
+    from demovlp_amd import functional as Fn, ops
+    obj, mask = data["object"], data["object_mask"]
+    dy = None
+    t0 = 0.0
+    for it in range(steps + 2):
+        if it == 2:
+            dist_sync()
+            t0 = time.perf_counter()
+        for p in model.object_model.parameters():
+            p.grad = None
+        emb, _ = model.object_model(obj, mask)
+        if dy is None:
+            dy = torch.randn(emb.shape, device=emb.device, dtype=torch.float32).mul_(1e-3).to(emb.dtype)
+        emb.backward(dy)
+        Fn.join_side_stream()
+        ops.flush_reductions()
+    dist_sync()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -100,14 +158,24 @@ def main():
                          "2 also weight-gradient GEMMs (+6%% pairs/s, but concurrent GEMMs stretch each other)")
     ap.add_argument("--p8", type=int, default=-1, help="override dvlp_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
+    ap.add_argument("--no-object-tower", action="store_true", help="skip the object-transformer-only fwd+bwd timing")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
+                         "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
+    ap.add_argument("--gather-negatives", action="store_true",
+                    help="cross-GPU negatives: all-gather the embeddings for the contrastive losses (opt-in; the reference trains "
+                         "with per-rank negatives, trainer/trainer_dist.py:148-165)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))          # before anything initialises the GPU in this process
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}")
+    import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -118,7 +186,7 @@ def main():
     from demovlp_amd import ops, synthetic as syn
     from demovlp_amd.loss import GlobalLocalLoss
     from demovlp_amd.model import ObjectRelation
-    from demovlp_amd.trainer import FusedAdamW, GradReducer, ParamArena, train_step
+    from demovlp_amd.trainer import FusedAdamW, GradReducer, GraphedTrainStep, ParamArena, train_step
 
     B, F, R = a.batch, a.frames, a.regions
     cdt = "bfloat16" if a.dtype == "bf16" else "float32"
@@ -132,8 +200,16 @@ def main():
         ops.call("dvlp_gemm_p8_mode", a.p8)
     arena = ParamArena(model, bf16_shadow=(a.dtype == "bf16"))
     opt = FusedAdamW(arena, lr=1e-5)
-    reducer = GradReducer(arena, bucket_mb=64.0, always_reduce=force_dist) if (world > 1 or force_dist) else None
     loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+    gather = None
+    if a.gather_negatives and (world > 1 or force_dist):
+        gather = argparse.Namespace(world_size=world, rank=rank)
+    use_graph = bool(a.graph) and gather is None and not a.overlap_wgrad
+    reducer, stepper = None, None
+    if use_graph:
+        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist)
+    elif world > 1 or force_dist:
+        reducer = GradReducer(arena, bucket_mb=64.0, always_reduce=force_dist)
 
     obj, mask = syn.fast_region_batch(B, F, R, seed=7 + rank)
     ids, att = syn.caption_batch(B, first_sample=rank * B)
@@ -145,26 +221,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        if stepper is not None:
+            return stepper(data)[0]
+        return train_step(model, loss_fn, opt, data, reducer, gather_negatives=gather)[0]
+
+    if use_graph:
+        a.warmup = max(a.warmup, 3)              # two eager steps + the capturing one must precede the timed region
     loss = None
-    for _ in range(a.warmup):
-        loss, _, _ = train_step(model, loss_fn, opt, data, reducer)
+    step1_loss = None
+    for i in range(a.warmup):
+        loss = step()
+        if i == 0:
+            step1_loss = float(loss.item())
     sync()
-    if not a.no_kernel_timing:
+    timing_inline = not a.no_kernel_timing and not use_graph
+    if timing_inline:
         ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss, _, _ = train_step(model, loss_fn, opt, data, reducer)
+        loss = step()
     host_elapsed = time.perf_counter() - t0          # time for the host to ENQUEUE the steps (launch-bound if ~= elapsed)
     sync()
     elapsed = time.perf_counter() - t0
+    final_loss = float(loss.item())
+    my_elapsed = elapsed
+    eager_ms = None
+    if not a.no_kernel_timing and use_graph:
+        # per-launch HIP events cannot be recorded inside a captured graph: the GEMM family is timed over an equally long EAGER
+        # region right behind the replayed one (same kernels, same shapes, same launch order, the stream they are launched on)
+        stepper._eager(data)
+        sync()
+        ops.prof_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            stepper._eager(data)
+        sync()
+        eager_ms = 1e3 * (time.perf_counter() - t1) / a.steps
     ops.prof_enable(False)
     gemm_ms, gemm_flops, gemm_n = ops.prof_collect() if not a.no_kernel_timing else (0.0, 0.0, 0)
-    final_loss = float(loss.item())
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+
+    # after the timed region: per-rank rates, a stand-alone all-reduce of the whole gradient arena, the object tower alone
+    per_rank = None
+    allreduce_ms = None
+    if world > 1 or force_dist:
+        rates = torch.zeros(world, device=dev, dtype=torch.float64)
+        rates[rank] = B * a.steps / my_elapsed
+        dist.all_reduce(rates)
+        per_rank = [round(float(x), 1) for x in rates.tolist()]
+        for it in range(4):
+            if it == 1:
+                sync()
+                t1 = time.perf_counter()
+            dist.all_reduce(arena.flat_g)
+        sync()
+        allreduce_ms = round(1e3 * (time.perf_counter() - t1) / 3, 3)
+    obj_s = None
+    if not a.no_object_tower:
+        obj_s = time_object_tower(model, data, max(3, min(a.steps, 10)), sync)
 
     if rank == 0:
         pairs = B * world * a.steps
@@ -179,30 +298,45 @@ def main():
             "config": {"workload": "configs/pt/o2t-cl-local-select-loss-cc.json arch+loss, F=%d frames x R=%d regions x 2048-d synthetic "
                                    "region features + random 100-token captions, per-GPU batch %d" % (F, R, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "optimizer": "fused HF-AdamW",
-                       "final_loss": round(final_loss, 4)},
+                       "negatives": "all-gathered" if gather is not None else "per-rank (reference default)",
+                       "step1_loss": None if step1_loss is None else round(step1_loss, 4), "final_loss": round(final_loss, 4)},
+            "launch_mode": "hipGraph replay (1 graph per step)" if use_graph else "eager",
             "host_enqueue_ms_per_step": round(1e3 * host_elapsed / a.steps, 3),
             "step_model_tflops": round(value * fpp / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * fpp / 1e12 / (peak * world), 4),
         }
+        if per_rank is not None:
+            out["per_rank_pairs_per_s"] = per_rank
+            out["grad_allreduce_ms_standalone"] = allreduce_ms
+            out["grad_allreduce_bytes"] = int(arena.flat_g.numel() * 4)
         if gemm_n:
             # HBM-side traffic per launch of the GEMM family cannot be self-measured from inside the process: it comes from
-            # the committed rocprofv3 PMC passes of this same command (profiles/r1_final_gemm_hbm_traffic_pmc.json)
-            traffic = None
-            for fn in ("r1_final_gemm_hbm_traffic_pmc.json", "r1_gemm_hbm_traffic_pmc.json"):
+            # the committed rocprofv3 PMC passes of this same command, regenerated every round (tools/profile_round.sh)
+            traffic, traffic_src = None, None
+            for fn in TRAFFIC_FILES:
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     if a.dtype == "bf16" and B == 64 and F == 8 and R == 36:
                         traffic = round(tj["gemm_family_traffic_bytes_per_launch"])
+                        traffic_src = "profiles/" + fn
                     break
                 except Exception:
                     pass
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline PMC pass)",
+                               "traffic_source": traffic_src,
                                "algorithmic_flops_per_launch": round(gemm_flops / gemm_n), "kernel": ("gemm_bf16_p8_kernel / gemm_bf16_p8_group_kernel / gemm_bf16_glds_kernel (all operand forms, incl. their split-K reductions)"
                                           if a.dtype == "bf16" else "gemm_f32_kernel (all forms)"),
                                "launches_per_step": gemm_n // a.steps, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
-                               "gemm_share_of_step": round(gemm_ms * 1e-3 / elapsed, 3)}
+                               "gemm_share_of_step": round(gemm_ms * 1e-3 / my_elapsed, 3),
+                               "timed_over": ("%d eager steps right behind the %d graph-replayed ones (%.3f ms/step eager)" % (a.steps, a.steps, eager_ms))
+                                             if eager_ms is not None else "the timed region itself"}
+            if obj_s is not None:
+                # north_star's target quantity: ObjectTransformer forward + backward alone, every kernel of it included
+                out["roofline"]["object_transformer_ms"] = round(1e3 * obj_s, 3)
+                out["roofline"]["object_transformer_tflops"] = round(B * fpp_obj / obj_s / 1e12, 2)
+                out["roofline"]["object_transformer_frac"] = round(B * fpp_obj / obj_s / 1e12 / peak, 4)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, R)
         print(json.dumps(out), flush=True)

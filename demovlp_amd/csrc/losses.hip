@@ -181,3 +181,65 @@ extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const voi
     else return DVLP_ERR_DTYPE;
     return dvlp_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rectangular sim_matrix (model/model.py:582-590 takes any [N,d] x [M,d]; the validation path hands it the whole eval
+// set, trainer/trainer_dist.py:369): rows are normalised here into fp32, the [N,M] product (and the two backward
+// products) run on the exact-fp32 GEMM, and the normalisation's backward is the second kernel.  One wave per row.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(int64_t M, const T* __restrict__ x, float* __restrict__ xn, float* __restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    float v[4];
+    l4<T>(x + r * LD_ + lane * 4, v);
+    const float n = sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+    const float rn = 1.f / fmaxf(n, 1e-8f);
+    *(float4*)(xn + r * LD_ + lane * 4) = make_float4(v[0] * rn, v[1] * rn, v[2] * rn, v[3] * rn);
+    if (lane == 0) norm[r] = n;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(int64_t M, const T* __restrict__ x, const float* __restrict__ norm,
+                                                          const float* __restrict__ dxn, T* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    float v[4], o[4];
+    l4<T>(x + r * LD_ + lane * 4, v);
+    const float4 g4 = *(const float4*)(dxn + r * LD_ + lane * 4);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float n = norm[r];
+    if (n > 1e-8f) {
+        const float proj = wave_sum(g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3]) / (n * n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = (g[c] - v[c] * proj) / n;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = g[c] / 1e-8f;
+    }
+    s4<T>(dx + r * LD_ + lane * 4, o);
+}
+
+extern "C" int dvlp_rownorm_fwd(int dtype, int64_t M, int64_t d, const void* x, float* xn, float* norm, void* stream) {
+    dvlp_clear_status();
+    if (d != LD_ || M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)cdiv(M, 4));
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(rownorm_fwd_kernel<float>, grid, dim3(256), 0, st, M, (const float*)x, xn, norm);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(rownorm_fwd_kernel<bf16>, grid, dim3(256), 0, st, M, (const bf16*)x, xn, norm);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+extern "C" int dvlp_rownorm_bwd(int dtype, int64_t M, int64_t d, const void* x, const float* norm, const float* dxn, void* dx, void* stream) {
+    dvlp_clear_status();
+    if (d != LD_ || M <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)cdiv(M, 4));
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(rownorm_bwd_kernel<float>, grid, dim3(256), 0, st, M, (const float*)x, norm, dxn, (float*)dx);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(rownorm_bwd_kernel<bf16>, grid, dim3(256), 0, st, M, (const bf16*)x, norm, dxn, (bf16*)dx);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}

@@ -46,3 +46,52 @@ extern "C" int dvlp_adamw_step(int64_t n, float* p, const float* g, float* m, fl
                        weight_decay, step_size, grad_scale, (bf16*)bf16_shadow);
     return dvlp_launch_status();
 }
+
+// Device-resident hyper-parameters: hyper = {lr, beta1, beta2, eps, weight_decay, grad_scale, step, step_size} (fp32; step is an
+// exact integer below 2^24).  The step counter advances ON THE DEVICE, so a hipGraph that captured one optimisation step replays
+// with the right bias correction every time, and the host changes lr / grad_scale by writing the buffer (no re-capture).
+__global__ void adamw_prep_kernel(float* __restrict__ hyper) {
+    const double step = (double)hyper[6] + 1.0;
+    const double bc1 = 1.0 - pow((double)hyper[1], step), bc2 = 1.0 - pow((double)hyper[2], step);
+    hyper[6] = (float)step;
+    hyper[7] = (float)((double)hyper[0] * sqrt(bc2) / bc1);
+}
+__global__ void adamw_dev_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 const float* __restrict__ hyper, bf16* __restrict__ shadow) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5], step_size = hyper[7];
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            float4 pp = *(float4*)(p + i), gg = *(const float4*)(g + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
+            float* P = (float*)&pp; float* G = (float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gr = G[j] * grad_scale;
+                M[j] = M[j] * b1 + gr * (1.f - b1);
+                V[j] = V[j] * b2 + gr * gr * (1.f - b2);
+                P[j] = P[j] - step_size * (M[j] / (sqrtf(V[j]) + eps));
+                if (wd > 0.f) P[j] = P[j] - P[j] * lr * wd;
+            }
+            *(float4*)(p + i) = pp; *(float4*)(m + i) = mm; *(float4*)(v + i) = vv;
+            if (shadow) { bf16x4 s; s[0] = (bf16)P[0]; s[1] = (bf16)P[1]; s[2] = (bf16)P[2]; s[3] = (bf16)P[3]; *(bf16x4*)(shadow + i) = s; }
+        } else {
+            for (int64_t k = i; k < n; ++k) {
+                const float gr = g[k] * grad_scale;
+                m[k] = m[k] * b1 + gr * (1.f - b1);
+                v[k] = v[k] * b2 + gr * gr * (1.f - b2);
+                float x = p[k] - step_size * (m[k] / (sqrtf(v[k]) + eps));
+                if (wd > 0.f) x = x - x * lr * wd;
+                p[k] = x;
+                if (shadow) shadow[k] = (bf16)x;
+            }
+        }
+    }
+}
+
+extern "C" int dvlp_adamw_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float* hyper, void* bf16_shadow, void* stream) {
+    dvlp_clear_status();
+    if (n <= 0 || !hyper) return DVLP_ERR_SHAPE;
+    int64_t blocks = cdiv(n, 1024); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (const float*)hyper, (bf16*)bf16_shadow);
+    return dvlp_launch_status();
+}

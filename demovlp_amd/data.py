@@ -73,48 +73,114 @@ def alternate(loaders: Sequence[Iterable]) -> Iterator[Tuple[int, object]]:
             yield i, b
 
 
+class _Staging:
+    """One set of pinned host buffers + the event that marks the end of the last host->device copy issued from them."""
+
+    def __init__(self, batch, frames, max_regions, pin):
+        mk = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt).pin_memory() if pin else torch.zeros(*s, dtype=dt)  # noqa: E731
+        self.feat, self.box = mk(batch, frames, max_regions, FEAT_DIM), mk(batch, frames, max_regions, 4)
+        self.conf, self.wh = mk(batch, frames, max_regions), mk(batch, frames, 2)
+        self.n = mk(batch, frames, dt=torch.int32)
+        self.copied = torch.cuda.Event() if pin else None
+        self.in_flight = False
+
+    def wait_reusable(self):
+        """Block the host until the DMA that last read these buffers has finished (they are about to be overwritten)."""
+        if self.in_flight:
+            self.copied.synchronize()
+            self.in_flight = False
+
+    def tensors(self):
+        return self.feat, self.box, self.conf, self.wh, self.n
+
+
 class RegionBatcher:
     """Raw frames of a batch -> `object [B,F,R,2054]` fp32 + `object_mask [B,F,R]` on the device.
 
     Frames may have different region counts (20-100 in the released features): they are packed into pinned host buffers of
-    `max_regions` rows with a per-frame valid count, copied asynchronously on `copy_stream`, and selected on the device."""
+    `max_regions` rows with a per-frame valid count, copied asynchronously on `copy_stream`, and selected on the device.
+    The pinned buffers are double-buffered (``nbuf``): the host fills set k+1 while the DMA of set k is still running, and a
+    set is only overwritten after the event recorded behind its last copy has completed."""
 
-    def __init__(self, batch: int, frames: int, regions: int, max_regions: int = 100, device: str | torch.device = "cuda"):
+    def __init__(self, batch: int, frames: int, regions: int, max_regions: int = 100, device: str | torch.device = "cuda", nbuf: int = 2):
         self.B, self.F, self.R, self.M = batch, frames, regions, max_regions
         self.device = torch.device(device)
         pin = self.device.type == "cuda"
-        mk = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt).pin_memory() if pin else torch.zeros(*s, dtype=dt)  # noqa: E731
-        self.h_feat, self.h_box = mk(batch, frames, max_regions, FEAT_DIM), mk(batch, frames, max_regions, 4)
-        self.h_conf, self.h_wh = mk(batch, frames, max_regions), mk(batch, frames, 2)
-        self.h_n = mk(batch, frames, dt=torch.int32)
+        self.bufs = [_Staging(batch, frames, max_regions, pin) for _ in range(max(1, nbuf))]
+        self.cur = 0
         self.copy_stream = torch.cuda.Stream(device=self.device) if pin else None
+        self.bytes_staged = 0
+
+    # the staging set being filled (kept as attributes for callers that peek at the buffers)
+    @property
+    def h_feat(self):
+        return self.bufs[self.cur].feat
+
+    @property
+    def h_conf(self):
+        return self.bufs[self.cur].conf
 
     def stage(self, b: int, f: int, x: np.ndarray, bbox: np.ndarray, conf: np.ndarray, wh: Tuple[float, float]) -> None:
         n = x.shape[0]
         if n > self.M:
             raise ValueError(f"frame has {n} regions, staging buffers hold {self.M}")
-        self.h_feat[b, f, :n] = torch.from_numpy(x)
-        self.h_box[b, f, :n] = torch.from_numpy(bbox)
-        self.h_conf[b, f, :n] = torch.from_numpy(conf)
-        self.h_conf[b, f, n:] = -1.0                              # never selected: real confidences are positive
-        self.h_wh[b, f, 0], self.h_wh[b, f, 1] = wh
-        self.h_n[b, f] = n
+        s = self.bufs[self.cur]
+        s.wait_reusable()
+        s.feat[b, f, :n] = torch.from_numpy(x)
+        s.box[b, f, :n] = torch.from_numpy(bbox)
+        s.conf[b, f, :n] = torch.from_numpy(conf)
+        s.conf[b, f, n:] = -1.0                                   # never selected: real confidences are positive
+        s.wh[b, f, 0], s.wh[b, f, 1] = wh
+        s.n[b, f] = n
 
     def stage_video(self, b: int, frame_dir: str, frame_idxs: Sequence[int]) -> None:
         for f, idx in enumerate(frame_idxs):
             self.stage(b, f, *read_frame_npz(os.path.join(frame_dir, f"{idx}.npz")))
 
     def to_device(self):
-        """-> (object [B,F,R,2054] f32, object_mask [B,F,R] f32, object_len [B,F] int32), all on the device."""
+        """-> (object [B,F,R,2054] f32, object_mask [B,F,R] f32, object_len [B,F] int32), all on the device.  Returns as soon as
+        the copies and the selection kernel are enqueued; the next batch may be staged immediately (into the other buffer set)."""
         from . import ops
         if self.device.type != "cuda":
             raise ops._lib.DemoVLPHipError("RegionBatcher.to_device needs a ROCm device: there is no CPU fallback")
+        s = self.bufs[self.cur]
         cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_stream(cur)                     # the previous batch's kernels may still read the device buffers
-            d = [t.to(self.device, non_blocking=True) for t in (self.h_feat, self.h_box, self.h_conf, self.h_wh, self.h_n)]
+            d = [t.to(self.device, non_blocking=True) for t in s.tensors()]
+            s.copied.record(self.copy_stream)
+        s.in_flight = True
+        self.bytes_staged += sum(t.numel() * t.element_size() for t in s.tensors())
         cur.wait_stream(self.copy_stream)
         for t in d:
             t.record_stream(cur)
+        self.cur = (self.cur + 1) % len(self.bufs)
         obj, mask, _order, lens = ops.region_select(d[0], d[1], d[2], d[3], self.R, nvalid=d[4])
         return obj, mask, lens
+
+
+def prefetching(batches: Iterable, depth: int = 2) -> Iterator:
+    """Run a batch iterator (file reads + staging + enqueueing of copies) on a background thread, ``depth`` batches ahead of the
+    consumer: host file I/O for batch k+1 overlaps the device step of batch k (the reference gets this from DataLoader workers,
+    base/base_data_loader.py:23-38)."""
+    import queue
+    import threading
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+    END = object()
+
+    def run():
+        try:
+            for b in batches:
+                q.put(b)
+            q.put(END)
+        except BaseException as e:  # noqa: BLE001
+            q.put(e)
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    while True:
+        item = q.get()
+        if item is END:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item

@@ -37,6 +37,14 @@ class ShadowCache:
         """Register an externally maintained shadow (a view of the fused optimizer's flat bf16 buffer)."""
         self._c[id(w)] = (w._version, shadow_view, w.data_ptr(), True)
 
+    def invalidate(self):
+        """The master weights changed behind autograd's back (the fused optimizer writes through raw pointers, so no version
+        counter moves): every shadow this cache maintains itself is re-cast on its next use.  Adopted (optimizer-written)
+        shadows are current by construction."""
+        for k, e in list(self._c.items()):
+            if not e[3]:
+                self._c[k] = (-1, e[1], e[2], False)
+
     def clear(self):
         self._c.clear()
 
@@ -218,7 +226,9 @@ class ObjectPrologueFn(torch.autograd.Function):
         feat, box = ops.obj_split(obj, cd)
         tok = ops.linear_fwd(feat, SHADOWS.get(Wo, cd), bo.detach())
         pos0 = pos_embed.detach()[0, 0].contiguous()
-        x, addmask = ops.embed_assemble(tok, box, Wp.detach(), bp.detach(), temporal.detach().reshape(F, 768), cls.detach().reshape(768),
+        # the FULL temporal_embed parameter comes in (curr_frames < num_frames uses its first F rows, object_transformer.py:423-432),
+        # so its gradient lands in the parameter's own arena slice like every other one
+        x, addmask = ops.embed_assemble(tok, box, Wp.detach(), bp.detach(), temporal.detach()[0, :F].contiguous(), cls.detach().reshape(768),
                                         pos0, mask01, B, F, R)
         ctx.save_for_backward(feat, box)
         ctx.params = (Wo, bo, Wp, bp, temporal, cls, pos_embed)
@@ -240,9 +250,13 @@ class ObjectPrologueFn(torch.autograd.Function):
                                                           # still be a deferred reduction here: it cannot be read and copied
         dWp = ops.box_wgrad(dtok, box, out=_grad_buf(Wp))
         # temporal[f] = sum over (b, r) of dtok[b, f, r, :]
-        gt = _grad_buf(temporal) if temporal.shape[1] == F else None
-        dtemp = ops.colsum_grouped(dtok, B * R, 768, 768, R, F * R * 768, F, R * 768, out=gt)
-        dtemp = dtemp if gt is not None else dtemp.reshape(1, F, 768)
+        gt = _grad_buf(temporal)
+        if gt is None:
+            gt = torch.empty_like(temporal, dtype=torch.float32)
+        if temporal.shape[1] > F:
+            gt[0, F:].zero_()                             # frames beyond the clip length receive no gradient
+        ops.colsum_grouped(dtok, B * R, 768, 768, R, F * R * 768, F, R * 768, out=gt[0, :F])
+        dtemp = gt
         dcls_row = ops.colsum_grouped(dx, B, 768, N * 768, B, 0, 1, 0).reshape(768)     # sum_b dx[b, 0, :]
         dcls = _into(cls, dcls_row.reshape(1, 1, 768))
         dpos = torch.zeros_like(pos_embed)
@@ -396,20 +410,40 @@ class BertLayerFn(torch.autograd.Function):
 # losses
 # ----------------------------------------------------------------------------------------------------------------
 class SimMatrixFn(torch.autograd.Function):
-    """model/model.py:582-590."""
+    """model/model.py:582-590 on [N,256] x [M,256].  The per-rank training shape (N == M <= 64) runs inside the one-workgroup
+    loss-head kernel; anything else (gathered negatives, the whole eval set) normalises rows once and uses the exact-fp32 GEMM."""
 
     @staticmethod
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
-        r = ops.global_local_loss(a, b, None, 0.05, 20.0, 1, 0, 1)
-        ctx.save_for_backward(a, b)
-        return r["sim"]
+        if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 256 or b.shape[1] != 256:
+            raise ops._lib.DemoVLPHipError(f"sim_matrix expects [N,256] x [M,256], got {tuple(a.shape)} x {tuple(b.shape)}")
+        if a.dtype != b.dtype:
+            b = b.to(a.dtype)
+        ops.require_gpu(a, b)
+        N, M = a.shape[0], b.shape[0]
+        ctx.fused = N == M and N <= 64
+        if ctx.fused:
+            r = ops.global_local_loss(a, b, None, 0.05, 20.0, 1, 0, 1)
+            ctx.save_for_backward(a, b)
+            return r["sim"]
+        an, na = ops.rownorm_fwd(a)
+        bn, nb = ops.rownorm_fwd(b)
+        ctx.save_for_backward(a, b, an, bn, na, nb)
+        return ops.gemm(an, bn, N, M, 256, dtype=ops.F32)
 
     @staticmethod
     def backward(ctx, dsim):
-        a, b = ctx.saved_tensors
-        r = ops.global_local_loss(a, b, None, 0.05, 20.0, 1, 0, 4, dsim=dsim.contiguous().float())
-        return r["dgt"], r["dgo"]
+        dsim = dsim.contiguous().float()
+        if ctx.fused:
+            a, b = ctx.saved_tensors
+            r = ops.global_local_loss(a, b, None, 0.05, 20.0, 1, 0, 4, dsim=dsim)
+            return r["dgt"], r["dgo"]
+        a, b, an, bn, na, nb = ctx.saved_tensors
+        N, M = a.shape[0], b.shape[0]
+        dan = ops.gemm(dsim, bn, N, 256, M, trans_b=True, ldb=256, dtype=ops.F32)                  # dsim   [N,M] . bn [M,256]
+        dbn = ops.gemm(dsim, an, M, 256, N, trans_a=True, lda=M, trans_b=True, ldb=256, dtype=ops.F32)   # dsim^T [M,N] . an [N,256]
+        return ops.rownorm_bwd(a, na, dan), ops.rownorm_bwd(b, nb, dbn)
 
 
 class NormSoftmaxFn(torch.autograd.Function):

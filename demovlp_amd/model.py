@@ -145,14 +145,13 @@ class ObjectRelation(nn.Module):
 
 
 def sim_matrix(a, b, eps=1e-8):
-    """model/model.py:582-590.  Rows are l2-normalised with max(|.|, 1e-8), then a_n b_n^T.  Host tensors (the
-    reference's validation path hands over .cpu() tensors) are staged through the GPU; without a GPU this raises."""
+    """model/model.py:582-590 for any [N,256] x [M,256].  Rows are l2-normalised with max(|.|, 1e-8), then a_n b_n^T.  Host
+    tensors (the reference's validation path hands over .cpu() tensors, trainer_dist.py:369) are staged through the GPU and the
+    result comes back on the host; without a GPU this raises."""
     if eps != 1e-8:
-        raise NotImplementedError("the kernel hard-codes eps = 1e-8 (the only value the reference uses)")
+        raise NotImplementedError("the kernels hard-code eps = 1e-8 (the only value the reference uses)")
     if a.is_cuda:
         return Fn.SimMatrixFn.apply(a, b)
     if not torch.cuda.is_available():
         raise DemoVLPHipError("sim_matrix needs an MI355X device (no CPU fallback)")
-    if a.shape[0] != b.shape[0]:
-        raise NotImplementedError("square similarity matrices only")
     return Fn.SimMatrixFn.apply(a.cuda().float(), b.cuda().float()).cpu()

@@ -95,9 +95,8 @@ class ObjectTransformer(nn.Module):
             raise ValueError(f"{F} frames > temporal_embed size {self.num_frames}")
         obj = x.contiguous().float()
         mask01 = x_mask.reshape(B, F, R).contiguous().float()
-        temporal = self.temporal_embed if F == self.num_frames else self.temporal_embed[:, :F]
         tok, addmask = Fn.ObjectPrologueFn.apply(obj, mask01, self.object_embedding.weight, self.object_embedding.bias,
-                                                 self.pos_embedding.weight, self.pos_embedding.bias, temporal, self.cls_token,
+                                                 self.pos_embedding.weight, self.pos_embedding.bias, self.temporal_embed, self.cls_token,
                                                  self.custom_pos_embed, self.compute_dtype)
         for blk in self.blocks:
             tok = blk(tok, addmask, F, R)

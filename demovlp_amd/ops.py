@@ -405,6 +405,21 @@ def global_local_loss(gt, go, xs, temperature, lam, use_global, use_local, stage
     return dict(sim=sim, dsim=dsim, dgt=dgt, dgo=dgo, dxs=dxs, losses=losses)
 
 
+def rownorm_fwd(x):
+    """x [M,256] -> (x / max(|x|, 1e-8) as fp32 [M,256], |x| fp32 [M])."""
+    M = x.shape[0]
+    xn = torch.empty((M, 256), device=x.device, dtype=torch.float32)
+    norm = torch.empty(M, device=x.device, dtype=torch.float32)
+    call("dvlp_rownorm_fwd", dt(x), M, 256, p(x), p(xn), p(norm), stream())
+    return xn, norm
+
+
+def rownorm_bwd(x, norm, dxn):
+    dx = torch.empty_like(x)
+    call("dvlp_rownorm_bwd", dt(x), x.shape[0], 256, p(x), p(norm), p(dxn.contiguous()), p(dx), stream())
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # region select, optimizer
 # ----------------------------------------------------------------------------------------------------------------
@@ -425,6 +440,11 @@ def region_select(feats, bbox, conf, wh, R, nvalid=None):
 def adamw_step(pflat, gflat, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, shadow=None):
     call("dvlp_adamw_step", pflat.numel(), p(pflat), p(gflat), p(m), p(v), float(lr), float(beta1), float(beta2), float(eps),
          float(weight_decay), int(step), float(grad_scale), p(shadow), stream())
+
+
+def adamw_step_dev(pflat, gflat, m, v, hyper, shadow=None):
+    """hyper: fp32 [8] device tensor {lr, b1, b2, eps, wd, grad_scale, step, step_size}; the step counter advances on the device."""
+    call("dvlp_adamw_step_dev", pflat.numel(), p(pflat), p(gflat), p(m), p(v), p(hyper), p(shadow), stream())
 
 
 def prof_enable(on: bool):

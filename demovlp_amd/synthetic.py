@@ -98,8 +98,9 @@ def caption_batch(batch: int, first_sample: int = 0, text_len: int = TEXT_LEN):
 # --------------------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------------------
-def state_dict_schema(num_frames: int, object_num: int) -> "dict[str, tuple]":
-    """Name -> shape of every tensor in ``ObjectRelation.state_dict()`` (280 tensors)."""
+def state_dict_schema(num_frames: int, object_num: int, time_module=None) -> "dict[str, tuple]":
+    """Name -> shape of every tensor in ``ObjectRelation.state_dict()`` (280 tensors, + 4 per block
+    with ``time_module='timeattn'``: model/object_transformer.py:227-234)."""
     D, Hd = 768, 3072
     s: "dict[str, tuple]" = {}
     s["text_model.embeddings.word_embeddings.weight"] = (VOCAB, D)
@@ -130,6 +131,11 @@ def state_dict_schema(num_frames: int, object_num: int) -> "dict[str, tuple]":
         s[p + "attn.qkv.bias"] = (3 * D,)
         s[p + "attn.proj.weight"] = (D, D)
         s[p + "attn.proj.bias"] = (D,)
+        if time_module == "timeattn":
+            s[p + "timeattn.qkv.weight"] = (3 * D, D)
+            s[p + "timeattn.qkv.bias"] = (3 * D,)
+            s[p + "timeattn.proj.weight"] = (D, D)
+            s[p + "timeattn.proj.bias"] = (D,)
         s[p + "norm2.weight"] = (D,)
         s[p + "norm2.bias"] = (D,)
         s[p + "mlp.fc1.weight"] = (Hd, D)
@@ -171,5 +177,5 @@ def fill_tensor(name: str, shape) -> np.ndarray:
     return (0.02 * z).astype(np.float32)
 
 
-def fill_state_dict(num_frames: int, object_num: int) -> "dict[str, np.ndarray]":
-    return {k: fill_tensor(k, shp) for k, shp in state_dict_schema(num_frames, object_num).items()}
+def fill_state_dict(num_frames: int, object_num: int, time_module=None) -> "dict[str, np.ndarray]":
+    return {k: fill_tensor(k, shp) for k, shp in state_dict_schema(num_frames, object_num, time_module).items()}

@@ -47,6 +47,9 @@ class ParamArena:
         named = [kv for kv in named if kv[1].dim() >= 2] + [kv for kv in named if kv[1].dim() < 2]
         self.params = [p for _, p in named]
         self.names = [n for n, _ in named]
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        # arena index of the k-th trainable parameter in module.parameters() order (the order optimizer checkpoints use)
+        self.model_order = [pos[id(p)] for p in module.parameters() if p.requires_grad]
         self.n_matrix = sum(1 for p in self.params if p.dim() >= 2)
         self._clean = set()       # slices known to hold zeros (tensors that never receive a gradient are zeroed once, not per step)
         device = device or self.params[0].device
@@ -92,44 +95,160 @@ class ParamArena:
 
 
 class FusedAdamW:
-    """HF AdamW (eps added to sqrt(v) before bias correction, decoupled decay, correct_bias=True) over a ParamArena."""
+    """HF AdamW (eps added to sqrt(v) before bias correction, decoupled decay, correct_bias=True) over a ParamArena.
 
-    def __init__(self, arena: ParamArena, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0):
+    ``state_dict()`` / ``load_state_dict()`` speak the layout the reference checkpoints carry (base/base_trainer.py:185-192
+    saves ``optimizer.state_dict()`` of transformers.AdamW built over ``filter(requires_grad, model.parameters())``,
+    train_dist_multi.py:60-64): ``{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [0..n-1]}]}``
+    with i counting the trainable parameters in ``model.parameters()`` order; tensors that never received a gradient have no
+    entry, as with the lazily created HF state."""
+
+    def __init__(self, arena: ParamArena, lr=1e-5, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if not correct_bias:
+            raise NotImplementedError("correct_bias=False is not used by the reference (train_dist_multi.py:64 keeps the default)")
         self.arena = arena
-        self.param_groups = [dict(params=arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.param_groups = [dict(params=arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=True)]
         self.m = torch.zeros_like(arena.flat_p)
         self.v = torch.zeros_like(arena.flat_p)
         self.step_count = 0
+        self._ever = set()            # arena indices that have received a gradient at least once (own HF-style state)
+        self._backwards = {}
+        self._hyper, self._hyper_host, self._hyper_step = None, None, 0
         if arena.flat_p.is_cuda:
             ops.enable_deferred_reductions(arena.flat_p.device)
+        # gradients are WRITTEN (not accumulated) into the arena by the backward kernels: a second backward() before step()
+        # would overwrite the first one's gradients, so count them (two sentinel tensors, one per tower) and refuse
+        want = ("object_model.proj.weight", "txt_proj.1.weight")
+        for i in ([i for i, n in enumerate(arena.names) if n.endswith(want)] or [0]):
+            arena.params[i].register_post_accumulate_grad_hook(lambda _p, i=i: self._backwards.__setitem__(i, self._backwards.get(i, 0) + 1))
 
     def zero_grad(self, set_to_none=True):
         for p in self.arena.params:
             p.grad = None
-        # gradients of tensors that received none this step must read as 0 for the flat update
-        self._need_zero = True
+        self._backwards = {}
 
-    def step(self, grad_scale=1.0):
+    def _adopt_stray_grads(self):
+        """Every gradient must live in its arena slice for the flat update (and the bucketed all-reduce).  The kernels write
+        there directly; a gradient autograd materialised elsewhere (a parameter used through a plain torch op) is copied in."""
+        for p in self.arena.params:
+            g = p.grad
+            if g is not None and g.data_ptr() != p._dvlp_grad_view.data_ptr():
+                p._dvlp_grad_view.copy_(g)
+
+    def prepare(self):
+        """Host-side part of a step: everything that inspects autograd state.  After it the flat gradient buffer is final."""
+        if any(c > 1 for c in self._backwards.values()):
+            raise RuntimeError("FusedAdamW: more than one backward() since zero_grad(): the arena path writes gradients in place and "
+                               "does not accumulate across backward passes (scale the loss / enlarge the batch instead)")
         Fn.join_side_stream()          # weight gradients may still be in flight on the side stream
-        if self.arena.flat_p.is_cuda:
-            ops.flush_reductions()     # bias / LayerNorm gradients: one batched final reduction (no-op when already flushed)
-        g = self.param_groups[0]
         a = self.arena
+        if a.flat_p.is_cuda:
+            ops.flush_reductions()     # bias / LayerNorm gradients: one batched final reduction (no-op when already flushed)
+        self._adopt_stray_grads()
         # tensors without a gradient this step (norm3.*, object_model.norm.*, ...) must not be updated: their slices read zero
         a.zero_untouched(lambda i: a.params[i].grad is not None)
+        self._ever.update(i for i in range(len(a.params)) if i not in a._clean)
+
+    def _sync_hyper(self, grad_scale):
+        g = self.param_groups[0]
+        want = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(grad_scale))
+        if self._hyper is None:
+            self._hyper = torch.zeros(8, device=self.arena.flat_p.device, dtype=torch.float32)
+            self._hyper_host = None
+        if want != self._hyper_host:
+            self._hyper[:6].copy_(torch.tensor(want, dtype=torch.float32))
+            self._hyper_host = want
+        if self._hyper_step != self.step_count:                 # after load_state_dict: the device counter follows the host's
+            self._hyper[6:7].fill_(float(self.step_count))
+            self._hyper_step = self.step_count
+
+    def launch(self, grad_scale=1.0):
+        """Device-side part: the fused update (hyper-parameters and the step counter live in device memory, so this launch can sit
+        inside a captured hipGraph and be replayed)."""
+        a = self.arena
+        self._sync_hyper(grad_scale)
+        ops.adamw_step_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s)
         self.step_count += 1
-        ops.adamw_step(a.flat_p, a.flat_g, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                       self.step_count, grad_scale, a.flat_s)
+        self._hyper_step = self.step_count
         if a.flat_s is not None:
             a.adopt_shadow()
+        else:
+            Fn.SHADOWS.invalidate()    # the masters moved without a version bump: bf16 shadows cast on demand are stale now
 
+    def replayed(self):
+        """A captured graph containing launch() was replayed: the device advanced its step counter, follow it on the host."""
+        self.step_count += 1
+        self._hyper_step = self.step_count
+
+    def step(self, grad_scale=1.0):
+        self.prepare()
+        self.launch(grad_scale)
+
+    # ---- checkpoint interchange (base/base_trainer.py:176-267) ----------------------------------------------------
     def state_dict(self):
-        return dict(step=self.step_count, m=self.m, v=self.v, param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        a = self.arena
+        state = {}
+        for k, i in enumerate(a.model_order):
+            if i in self._ever:
+                lo, hi = a.slice_of(i)
+                shape = a.params[i].shape
+                state[k] = dict(step=self.step_count, exp_avg=self.m[lo:hi].view(shape).clone(), exp_avg_sq=self.v[lo:hi].view(shape).clone())
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(a.model_order)))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.step_count = sd["step"]
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
+        a = self.arena
+        self.m.zero_()
+        self.v.zero_()
+        self._ever = set()
+        steps = set()
+        for k, st in sd["state"].items():
+            i = a.model_order[int(k)]
+            lo, hi = a.slice_of(i)
+            self.m[lo:hi].copy_(st["exp_avg"].reshape(-1))
+            self.v[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+            self._ever.add(i)
+        if len(steps) > 1:
+            raise NotImplementedError(f"per-parameter step counts differ ({sorted(steps)}): the fused kernel keeps one step counter")
+        self.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in g:
+                self.param_groups[0][k] = tuple(g[k]) if k == "betas" else g[k]
+
+
+def adjust_learning_rate(optimizer, epoch, args):
+    """trainer/trainer_dist.py:97-102, called at the END of every epoch (:198): every group's lr becomes ``args.learning_rate1``
+    (default 2e-4, train_dist_multi.py:173) x 0.1 per milestone of ``args.schedule`` already passed -- so epoch 1 runs at the
+    config's lr and every later epoch at learning_rate1 unless -lr1 is given.  Reproduced verbatim, quirk included."""
+    lr = args.learning_rate1
+    for milestone in args.schedule:
+        lr *= 0.1 if epoch >= milestone else 1.0
+    for param_group in optimizer.param_groups:
+        param_group["lr"] = lr
+    return lr
+
+
+def save_checkpoint(path, model, optimizer, epoch, monitor_best=0.0, config=None):
+    """The reference's checkpoint file (base/base_trainer.py:185-192): same keys, same nesting."""
+    torch.save({"arch": type(model).__name__, "epoch": epoch, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
+                "monitor_best": monitor_best, "config": config}, path)
+
+
+def resume_checkpoint(path, model, optimizer, map_location="cpu"):
+    """base/base_trainer.py:202-267: model weights (``module.`` prefix added / stripped as needed) and optimizer state.
+    Returns (start_epoch, monitor_best)."""
+    from .model import state_dict_data_parallel_fix
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(state_dict_data_parallel_fix(ck["state_dict"], model.state_dict()))
+    if isinstance(optimizer, FusedAdamW) and optimizer.arena.flat_s is not None:
+        optimizer.arena.refresh_shadow()
+    else:
+        Fn.SHADOWS.invalidate()
+    optimizer.load_state_dict(ck["optimizer"])
+    return ck["epoch"] + 1, ck["monitor_best"]
 
 
 class GradReducer:
@@ -228,15 +347,34 @@ class GradReducer:
         return 1.0 / self.world          # fold the DDP average into the optimizer's grad_scale
 
 
-def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = None):
-    """One optimisation step on an already-tokenised, already-on-device batch (trainer/trainer_dist.py:144-171)."""
+def _gather_plain(t, world, group=None):
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return torch.cat(out, 0)
+
+
+def gather_embeddings(out, text_length, text_mask, args):
+    """Cross-GPU negatives (opt-in; the reference binds ``self.allgather = AllGather_multi.apply`` at trainer_dist.py:82 and never
+    calls it in ``_train_epoch``): every rank sees the embeddings of all ranks, concatenated in rank order, with the reference's
+    backward (the local slice of the incoming gradient, no reduce-scatter -- trainer_dist.py:25-31).  Masks and lengths carry no
+    gradient and are gathered plainly."""
+    n_gpu = args.world_size
+    g = lambda t: AllGather_multi.apply(t, n_gpu, args)  # noqa: E731
+    gathered = dict(global_text_embeddings=g(out["global_text_embeddings"]), local_text_embeddings=g(out["local_text_embeddings"]),
+                    global_object_embeddings=g(out["global_object_embeddings"]), local_object_embeddings=g(out["local_object_embeddings"]),
+                    object_mask=_gather_plain(out["object_mask"], n_gpu))
+    return gathered, _gather_plain(text_length, n_gpu), _gather_plain(text_mask, n_gpu)
+
+
+def forward_backward(model, loss_fn, data, gather_negatives=None):
+    """trainer/trainer_dist.py:148-165: forward, masks, sim_matrix, GlobalLocalLoss, backward (+ the batched final reduction of the
+    bias / LayerNorm gradients).  Returns the three detached losses."""
     text_length = torch.sum(data["text"]["attention_mask"], dim=1)
-    optimizer.zero_grad()
-    if reducer is not None:
-        reducer.begin()
     out = model(data)
     text_mask = data["text"]["attention_mask"][:, 1:].contiguous()
     text_mask = (text_mask - 1.0) * 100.0
+    if gather_negatives is not None:
+        out, text_length, text_mask = gather_embeddings(out, text_length, text_mask, gather_negatives)
     global_sim = sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"])
     loss, global_loss, local_loss = loss_fn(global_sim, out["local_object_embeddings"], out["local_text_embeddings"],
                                             out["object_mask"], text_length, text_mask)
@@ -244,6 +382,17 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
     if loss.is_cuda:
         Fn.join_side_stream()          # deferred partial sums may have been produced on the side stream
         ops.flush_reductions()
+    return loss.detach(), global_loss.detach(), local_loss.detach()
+
+
+def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = None, gather_negatives=None):
+    """One optimisation step on an already-tokenised, already-on-device batch (trainer/trainer_dist.py:144-171).
+    ``gather_negatives``: None (reference behaviour: per-rank negatives) or an object with ``world_size`` / ``rank`` (the
+    reference's ``args``) to run the contrastive losses over the all-gathered embeddings of every rank."""
+    optimizer.zero_grad()
+    if reducer is not None:
+        reducer.begin()
+    losses = forward_backward(model, loss_fn, data, gather_negatives)
     scale = reducer.finish() if reducer is not None else 1.0
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(grad_scale=scale)
@@ -253,4 +402,131 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
                 if p.grad is not None:
                     p.grad.mul_(scale)
         optimizer.step()
-    return loss.detach(), global_loss.detach(), local_loss.detach()
+    return losses
+
+
+class GraphedTrainStep:
+    """``train_step`` as ONE hipGraph: after ``warmup`` eager steps (kernel attributes set, workspaces allocated, the deferred-
+    reduction table uploaded, the grad-less tensors learnt) the next step is captured -- forward, losses, backward, the batched
+    final reduction, fused AdamW: ~520 launches -- and every later call copies the batch into the captured input buffers and
+    replays.  The host's per-launch Python / ctypes / autograd cost (~40 us x 520) disappears from the step.
+
+    Data parallel (``world > 1``): the gradient all-reduce is NOT captured (no collective inside a graph): the graph ends after
+    backward, the arena's gradients are all-reduced in bucket-sized pieces on the same stream, and the optimizer launch follows
+    eagerly.  Static shapes only: a batch of another shape re-captures."""
+
+    def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 256.0, always_reduce: bool = False):
+        self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        self.warmup, self.calls = max(1, warmup), 0
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket = int(bucket_mb * 1024 * 1024 / 4)
+        # always_reduce: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
+        self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
+        self.graph, self.static, self.out, self.shape_key = None, None, None, None
+
+    @staticmethod
+    def _key(data):
+        return tuple((tuple(t.shape), t.dtype) for t in (data["text"]["input_ids"], data["text"]["attention_mask"], data["object"], data["object_mask"]))
+
+    def _allreduce(self):
+        g = self.opt.arena.flat_g
+        for lo in range(0, g.numel(), self.bucket):
+            dist.all_reduce(g[lo:lo + self.bucket], op=dist.ReduceOp.SUM, group=self.group)
+
+    def _eager(self, data):
+        self.opt.zero_grad()
+        losses = forward_backward(self.model, self.loss_fn, data)
+        self.opt.prepare()
+        if self.collective:
+            self._allreduce()
+        self.opt.launch(grad_scale=1.0 / self.world)
+        return losses
+
+    def _capture(self, data):
+        self.static = {"text": {k: v.clone() for k, v in data["text"].items()}, "object": data["object"].clone(),
+                       "object_mask": data["object_mask"].clone()}
+        self.shape_key = self._key(data)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt._sync_hyper(1.0 / self.world)              # no host->device copy may happen inside the capture
+        with torch.cuda.graph(self.graph):
+            self.opt.zero_grad()
+            self.out = forward_backward(self.model, self.loss_fn, self.static)
+            self.opt.prepare()
+            if not self.collective:
+                self.opt.launch(grad_scale=1.0)
+        if not self.collective:
+            self.opt.step_count -= 1                          # launch() counted a step, but capturing executed nothing
+
+    def __call__(self, data):
+        self.calls += 1
+        if self.graph is None or self._key(data) != self.shape_key:
+            if self.calls <= self.warmup:
+                return self._eager(data)
+            self._capture(data)
+        else:
+            for k, v in data["text"].items():
+                self.static["text"][k].copy_(v, non_blocking=True)
+            self.static["object"].copy_(data["object"], non_blocking=True)
+            self.static["object_mask"].copy_(data["object_mask"], non_blocking=True)
+        self.graph.replay()
+        if not self.collective:
+            self.opt.replayed()
+        else:
+            self._allreduce()
+            self.opt.launch(grad_scale=1.0 / self.world)
+        return self.out
+
+
+def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False, log=None):
+    """Retrieval evaluation of one validation loader, mirroring ``Multi_ObjectTrainer_dist._valid_epoch``
+    (trainer/trainer_dist.py:205-408) on already-tokenised batches ``{'text': {input_ids, attention_mask}, 'object', 'object_mask'}``:
+
+      per batch (:236-346)   forward without gradients, all-gather of lengths / masks / the four embedding tensors / the object
+                             mask when a process group with more than one rank is up (:252-321), per-batch validation loss
+      after the loop (:358-399)  ``o2t_sims = sim_matrix(text, object)`` (text x video) PLUS ``get_sim_by_segment(local_object,
+                             local_text, ...)`` (video x text) -- the two addends have transposed orientations and are added
+                             element-wise exactly as the reference does (it only type-checks on square eval sets); then every
+                             metric on ``o2t_sims``.
+
+    The embeddings stay in HBM (the reference parks them on the host between batches; 1000 MSRVTT pairs are 0.35 GB here).
+    Returns ``{'val_loss', 'o2t_sims' (numpy [N,N]), 'global_sims', 'local_sims', 'nested_val_metrics': {name: dict}}``."""
+    from . import metric as M
+    metrics = metrics if metrics is not None else (M.t2v_metrics, M.v2t_metrics)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    gather = (lambda t: _gather_plain(t, world)) if world > 1 else (lambda t: t)
+    acc = {k: [] for k in ("gt", "go", "lt", "lo", "len", "om", "tm")}
+    total, nb = 0.0, 0
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for data in batches:
+            att = data["text"]["attention_mask"]
+            text_length = gather(torch.sum(att, dim=1))
+            text_mask = (gather(att[:, 1:].contiguous()) - 1.0) * 100.0
+            out = model(data, return_embeds=True)
+            gt, go = gather(out["global_text_embeddings"]), gather(out["global_object_embeddings"])
+            lt, lo = gather(out["local_text_embeddings"]), gather(out["local_object_embeddings"])
+            om = gather(out["object_mask"])
+            for k, v in zip(acc, (gt, go, lt, lo, text_length, om, text_mask)):
+                acc[k].append(v)
+            loss, gl, ll = loss_fn(sim_matrix(gt, go), lo, lt, om, text_length, text_mask)
+            if log is not None:
+                log("loss:{}, global_loss: {}, local_loss: {}".format(loss.item(), gl.item(), ll.item()))
+            total += float(loss.item())
+            nb += 1
+        cat = {k: torch.cat(v) for k, v in acc.items()}
+        if mscoco:                                              # :363-366
+            cat["go"], cat["lo"], cat["om"] = cat["go"][::5], cat["lo"][::5], cat["om"][::5]
+        global_sims = sim_matrix(cat["gt"], cat["go"]).detach().float().cpu().numpy()
+        o2t_sims, local_sims = global_sims, None
+        if use_local:
+            local_sims = loss_fn.local_loss.get_sim_by_segment(cat["lo"], cat["lt"], cat["om"], cat["len"], cat["tm"], device=cat["lo"].device)
+            o2t_sims = global_sims + local_sims                 # [n_text, n_video] + [n_video, n_text]: the reference's addend quirk
+    if was_training:
+        model.train()
+    nested = {}
+    for fn in metrics:
+        nested[fn.__name__] = fn(o2t_sims, fold=5) if mscoco else fn(o2t_sims)
+    return dict(val_loss=total / max(nb, 1), o2t_sims=o2t_sims, global_sims=global_sims, local_sims=local_sims, nested_val_metrics=nested)

@@ -138,9 +138,19 @@ int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, cons
                            float lam, int use_global, int use_local, int stages, float* sim, float* dsim, void* dgt, void* dgo,
                            float* dxs, float* losses, void* stream);
 
+/* rectangular sim_matrix (model/model.py:582-590 on [N,256] x [M,256], e.g. the whole eval set at trainer/trainer_dist.py:369):
+   xn (fp32) = x / max(|x|, 1e-8) row-wise and norm = |x|; the [N,M] product and its two gradient products are dvlp_gemm calls in
+   DVLP_F32; dvlp_rownorm_bwd takes d loss / d xn back through the normalisation */
+int dvlp_rownorm_fwd(int dtype, int64_t M, int64_t d, const void* x, float* xn, float* norm, void* stream);
+int dvlp_rownorm_bwd(int dtype, int64_t M, int64_t d, const void* x, const float* norm, const float* dxn, void* dx, void* stream);
+
 /* ---- optimizer: transformers.AdamW as constructed at train_dist_multi.py:64 ---- */
 int dvlp_adamw_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, float grad_scale, void* bf16_shadow, void* stream);
+/* same update with the hyper-parameters in DEVICE memory: hyper[8] fp32 = {lr, beta1, beta2, eps, weight_decay, grad_scale, step,
+   step_size}; each call first advances hyper[6] (the step counter) and recomputes hyper[7] on the device, so one captured hipGraph of
+   a training step replays with the right bias correction, and lr / grad_scale change by writing the buffer */
+int dvlp_adamw_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float* hyper, void* bf16_shadow, void* stream);
 
 #ifdef __cplusplus
 }

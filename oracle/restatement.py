@@ -66,13 +66,14 @@ def region_select(feats, bbox, conf, image_w, image_h, object_num):
 # ==================================================================================================
 # A2-A6  object transformer
 # ==================================================================================================
-def structural_attention_mask(F_, R, device=None):
-    """Boolean [N,N] (N=1+F*R): query i may see key j iff i is CLS, or j is CLS, or same frame.
+def structural_attention_mask(F_, R, device=None, time=False):
+    """Boolean [N,N] (N=1+F*R): query i may see key j iff i is CLS, or j is CLS, or same frame (space attention,
+    'b (f n) d -> (b f) n d') / same region slot (time attention, 'b (f n) d -> (b n) f d').
 
-    Equivalent form of VarAttention's CLS-splice + per-frame rearrange (model/object_transformer.py:162-189)."""
+    Equivalent form of VarAttention's CLS-splice + rearrange (model/object_transformer.py:162-189)."""
     N = 1 + F_ * R
     frame = torch.full((N,), -1, dtype=torch.long, device=device)
-    frame[1:] = torch.arange(F_ * R, device=device) // R
+    frame[1:] = (torch.arange(F_ * R, device=device) % R) if time else (torch.arange(F_ * R, device=device) // R)
     same = frame[:, None] == frame[None, :]
     allow = same | (frame[None, :] == -1) | (frame[:, None] == -1)
     return allow
@@ -91,20 +92,20 @@ def object_prologue(p, obj, mask01):
     tok = feat @ p[pre + "object_embedding.weight"].t() + p[pre + "object_embedding.bias"]
     tok = tok + box @ p[pre + "pos_embedding.weight"].t() + p[pre + "pos_embedding.bias"]
     tok = tok.reshape(B, F_ * R, EMBED)
-    tok = tok + p[pre + "temporal_embed"][0].repeat_interleave(R, dim=0)[None]       # :425-432
+    tok = tok + p[pre + "temporal_embed"][0, :F_].repeat_interleave(R, dim=0)[None]  # :425-432 (curr_frames <= num_frames: first F rows)
     cls = (p[pre + "cls_token"][0, 0] + p[pre + "custom_pos_embed"][0, 0])[None, None].expand(B, 1, EMBED)
     x = torch.cat([cls, tok], dim=1)
     m = torch.cat([torch.ones(B, 1, dtype=mask01.dtype, device=mask01.device), mask01.reshape(B, -1)], dim=1)
     return x, (m - 1.0) * 100.0                                                       # :421
 
 
-def space_attention(qkv, add_mask, F_, R):
+def space_attention(qkv, add_mask, F_, R, time=False):
     """A4: qkv [B,N,2304] -> [B,N,768].  Full attention under the structural mask plus additive key mask."""
     B, N, _ = qkv.shape
     q, k, v = qkv.reshape(B, N, 3, HEADS, HEAD_DIM).permute(2, 0, 3, 1, 4)           # [B,H,N,64]
     s = (q * HEAD_DIM ** -0.5) @ k.transpose(-1, -2)                                  # :160
     s = s + add_mask[:, None, None, :].to(s.dtype)
-    allow = structural_attention_mask(F_, R, qkv.device)
+    allow = structural_attention_mask(F_, R, qkv.device, time)
     s = s.masked_fill(~allow[None, None], float("-inf"))
     a = torch.softmax(s, dim=-1)
     return (a @ v).transpose(1, 2).reshape(B, N, EMBED)
@@ -115,8 +116,16 @@ def gelu_erf(x):
 
 
 def vit_block(p, pre, x, add_mask, F_, R):
-    """A3/A5: SpaceTimeBlock with time_module falsy (model/object_transformer.py:249-274)."""
-    h = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-6)
+    """A3/A5: SpaceTimeBlock (model/object_transformer.py:249-274).  With the 'timeattn' weights present (time_module='timeattn',
+    :252-258): time attention over norm3(x) first, space attention on norm1(x + time), and -- the FrozenInTime residual --
+    the space output is added to the block INPUT x, not to the time residual (:267)."""
+    xin = x
+    if pre + "timeattn.qkv.weight" in p:
+        h3 = layer_norm(x, p[pre + "norm3.weight"], p[pre + "norm3.bias"], 1e-6)
+        tq = h3 @ p[pre + "timeattn.qkv.weight"].t() + p[pre + "timeattn.qkv.bias"]
+        ta = space_attention(tq, add_mask, F_, R, time=True)
+        xin = x + ta @ p[pre + "timeattn.proj.weight"].t() + p[pre + "timeattn.proj.bias"]
+    h = layer_norm(xin, p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-6)
     qkv = h @ p[pre + "attn.qkv.weight"].t() + p[pre + "attn.qkv.bias"]
     a = space_attention(qkv, add_mask, F_, R)
     x1 = x + a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
@@ -265,13 +274,15 @@ def rwa_loss(scores, lam=20.0):
     return (torch.softmax(z, 1) * (torch.log_softmax(z, 1) - torch.log(eye + 1e-6))).sum(1).mean()
 
 
-def global_local_loss(out, text_mask_add, lam=20.0, temperature=0.05, gate=True):
+def global_local_loss(out, text_mask_add, lam=20.0, temperature=0.05, gate=True, batched=None):
     """A11 + the trainer's glue (trainer/trainer_dist.py:156-164).  ``out`` is model_forward's dict,
     ``text_mask_add`` = (attention_mask[:,1:] - 1) * 100.  Returns (loss, global, local, sim, xattn)."""
     sim = sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"])
     g = norm_softmax_loss(sim, temperature)
-    xs = xattn_scores(out["local_object_embeddings"], out["local_text_embeddings"],
-                      out["object_mask"].to(torch.float32), text_mask_add.to(torch.float32), lam, gate)
+    if batched is None:
+        batched = out["local_object_embeddings"].shape[0] > 4      # the all-pairs form (what the reference materialises) beyond a few pairs
+    xs = (xattn_scores_batched if batched else xattn_scores)(out["local_object_embeddings"], out["local_text_embeddings"],
+                                                            out["object_mask"].to(torch.float32), text_mask_add.to(torch.float32), lam, gate)
     l = rwa_loss(xs, lam)
     return g + l, g, l, sim, xs
 

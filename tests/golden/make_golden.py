@@ -59,13 +59,13 @@ def import_reference():
     return ref_model, ref_loss, ref_data, scratch
 
 
-def build_reference_model(ref_model, F, R):
+def build_reference_model(ref_model, F, R, time_module=""):
     m = ref_model.ObjectRelation(
-        object_params={"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": ""},
+        object_params={"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": time_module},
         text_params={"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text",
                      "two_outputs": True})
     sd = m.state_dict()
-    schema = syn.state_dict_schema(F, R)
+    schema = syn.state_dict_schema(F, R, time_module or None)
     assert set(sd.keys()) == set(schema.keys()), set(sd.keys()) ^ set(schema.keys())
     with torch.no_grad():
         for k, v in sd.items():
@@ -116,8 +116,8 @@ def golden_region_select(ref_data, scratch):
     print("g1 written", len(out))
 
 
-def golden_model(ref_model, ref_loss, ref_data, scratch, F, R, B, tag, with_grads=True):
-    m = build_reference_model(ref_model, F, R)
+def golden_model(ref_model, ref_loss, ref_data, scratch, F, R, B, tag, with_grads=True, time_module=""):
+    m = build_reference_model(ref_model, F, R, time_module)
     objs, masks = [], []
     for s in range(B):
         o, mk, _ = reference_clip(ref_data, scratch, s, F, R)
@@ -171,7 +171,8 @@ def golden_model(ref_model, ref_loss, ref_data, scratch, F, R, B, tag, with_grad
                 res["grad/" + k] = g
             elif any(t in k for t in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc1.weight", "object_embedding.weight",
                                       "layer.0.attention.q_lin.weight", "layer.5.ffn.lin2.weight", "txt_proj.1.weight",
-                                      "object_model.proj.weight", "word_embeddings.weight", "blocks.6.attn.proj.weight")):
+                                      "object_model.proj.weight", "word_embeddings.weight", "blocks.6.attn.proj.weight",
+                                      "blocks.0.timeattn.qkv.weight", "blocks.11.timeattn.proj.weight")):
                 idx = rng.integers(0, g.size, 256)
                 res["gradidx/" + k] = idx
                 res["gradval/" + k] = g.reshape(-1)[idx]
@@ -187,6 +188,17 @@ def golden_model(ref_model, ref_loss, ref_data, scratch, F, R, B, tag, with_grad
 def golden_xattn(ref_loss):
     """xattn_score_fast on free-standing random embeddings (G4), incl. the f64 mask quirk of the real caller."""
     out = {}
+    # focal-gate margins (model/loss.py:274-283: H = [x * L - sum(x) > 0]): the gate is a hard threshold, so record how close to
+    # it the fixtures' probabilities sit -- tests may only tolerate a flipped gate where |margin| is below fp32 resolution
+    margins = []
+    orig_focal = ref_loss.focal_equal
+
+    def recording_focal(attn, batch_size, queryL, sourceL):
+        mg = (attn * sourceL - torch.sum(attn, dim=-1, keepdim=True)).detach().double().abs().reshape(-1)
+        margins.append(mg.numpy())
+        return orig_focal(attn, batch_size, queryL, sourceL)
+
+    ref_loss.focal_equal = recording_focal
     for B, G, W in ((2, 288, 99), (4, 288, 99), (8, 240, 99), (3, 30, 99), (2, 1152, 99)):
         rng = np.random.default_rng(1000 + B + G)
         im = rng.standard_normal((B, G, 256), dtype=np.float32)
@@ -212,6 +224,12 @@ def golden_xattn(ref_loss):
         out[key + "_scores"] = s.numpy()
         out[key + "_scores_nogate"] = s_nogate.numpy()
         out[key + "_rwa"] = np.array([rwa.item()])
+    ref_loss.focal_equal = orig_focal
+    mg = np.concatenate(margins)
+    edges = np.array([0.0, 1e-12, 1e-10, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, np.inf])
+    out["gate_margin_edges"] = edges
+    out["gate_margin_hist"] = np.histogram(mg, bins=edges)[0].astype(np.int64)
+    out["gate_margin_min"] = np.array([mg.min()])
     # NormSoftmaxLoss + sim_matrix on random vectors
     rng = np.random.default_rng(5)
     a = rng.standard_normal((16, 256), dtype=np.float32)
@@ -268,10 +286,140 @@ def golden_metrics(ref_loss):
     print("g7 written")
 
 
+class HFAdamW(torch.optim.Optimizer):
+    """transformers.AdamW 4.10.0 (the optimizer train_dist_multi.py:64 builds; absent from the container's transformers 5.15),
+    restated from its published update: m, v EMAs; denom = sqrt(v) + eps; step = lr * sqrt(1 - b2^t) / (1 - b1^t);
+    p -= step * m / denom; decoupled weight decay p -= lr * wd * p."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                b1, b2 = group["betas"]
+                st["step"] += 1
+                st["exp_avg"].mul_(b1).add_(p.grad, alpha=1.0 - b1)
+                st["exp_avg_sq"].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
+                denom = st["exp_avg_sq"].sqrt().add_(group["eps"])
+                step_size = group["lr"]
+                if group["correct_bias"]:
+                    step_size = step_size * (1.0 - b2 ** st["step"]) ** 0.5 / (1.0 - b1 ** st["step"])
+                p.addcdiv_(st["exp_avg"], denom, value=-step_size)
+                if group["weight_decay"] > 0.0:
+                    p.add_(p, alpha=-group["lr"] * group["weight_decay"])
+
+
+def _reference_batch(ref_data, scratch, F, R, B, first=0):
+    objs, masks = [], []
+    for s in range(first, first + B):
+        o, mk, _ = reference_clip(ref_data, scratch, s, F, R)
+        objs.append(o)
+        masks.append(torch.from_numpy(mk))
+    ids, att = syn.caption_batch(B, first_sample=first)
+    return {"text": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(att)},
+            "object": torch.stack(objs), "object_mask": torch.stack(masks)}
+
+
+def golden_loss_curve(ref_model, ref_loss, ref_data, scratch):
+    """G8: 10 optimisation steps of the reference model exactly as trainer/trainer_dist.py:144-171 drives them (zero_grad, forward,
+    sim_matrix, GlobalLocalLoss, backward, step) with HF-AdamW at the config's lr (1e-5) and at the lr the reference's
+    _adjust_learning_rate quirk switches to after epoch 1 (2e-4).  Also: the optimizer state_dict layout after those steps."""
+    F, R, B = 8, 36, 2
+    out = {}
+    for tag, lr in (("lr1e-5", 1e-5), ("lr2e-4", 2e-4)):
+        m = build_reference_model(ref_model, F, R)
+        data = _reference_batch(ref_data, scratch, F, R, B)
+        opt = HFAdamW(filter(lambda p: p.requires_grad, m.parameters()), lr=lr)
+        loss_fn = ref_loss.GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+        curve = []
+        for step in range(10):
+            opt.zero_grad()
+            o = m(data)
+            text_mask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+            text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+            gsim = ref_model.sim_matrix(o["global_text_embeddings"], o["global_object_embeddings"])
+            loss, gl, ll = loss_fn(gsim, o["local_object_embeddings"], o["local_text_embeddings"], o["object_mask"], text_length, text_mask)
+            loss.backward()
+            opt.step()
+            curve.append([loss.item(), gl.item(), ll.item()])
+        out[tag] = np.array(curve, np.float64)
+        print("g8", tag, out[tag][:, 0])
+        if tag == "lr2e-4":
+            sd = opt.state_dict()
+            names = [n for n, p in m.named_parameters() if p.requires_grad]
+            out["opt_state_keys"] = np.array(sorted(sd["state"].keys()), np.int64)
+            out["opt_param_names"] = np.array(names)
+            k = names.index("txt_proj.1.weight")
+            out["opt_txt_proj_exp_avg"] = sd["state"][k]["exp_avg"].numpy()
+            out["opt_txt_proj_exp_avg_sq"] = sd["state"][k]["exp_avg_sq"].numpy()
+            out["opt_txt_proj_weight"] = m.txt_proj[1].weight.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "g8_loss_curve.npz"), **out)
+
+
+def golden_eval(ref_model, ref_loss, ref_data, scratch):
+    """G9: the reference's retrieval evaluation (trainer/trainer_dist.py:205-408 with n_gpu = 1) on a synthetic MSRVTT-shape set:
+    configs/ft/msrvtt_o2t-select.json geometry (F=8, R=30), 96 video-caption pairs in batches of 32.  Per-batch validation loss,
+    o2t_sims = sim_matrix(text, object) + get_sim_by_segment(local_object, local_text, ...) with the reference's own
+    (transposed-addend) orientation, then t2v / v2t metrics from the reference's model/metric.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("refmetric", "/root/reference/model/metric.py")
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    F, R, BS, NB = 8, 30, 32, 3
+    m = build_reference_model(ref_model, F, R)
+    m.eval()
+    loss_fn = ref_loss.GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+    acc = {k: [] for k in ("gt", "go", "lt", "lo", "len", "om", "tm")}
+    val = []
+    with torch.no_grad():
+        for b in range(NB):
+            data = _reference_batch(ref_data, scratch, F, R, BS, first=b * BS)
+            text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+            text_mask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+            o = m(data, return_embeds=True)
+            for k, v in zip(acc, (o["global_text_embeddings"], o["global_object_embeddings"], o["local_text_embeddings"],
+                                  o["local_object_embeddings"], text_length, o["object_mask"], text_mask)):
+                acc[k].append(v)
+            loss, gl, ll = loss_fn(ref_model.sim_matrix(o["global_text_embeddings"], o["global_object_embeddings"]), o["local_object_embeddings"],
+                                   o["local_text_embeddings"], o["object_mask"], text_length, text_mask)
+            val.append([loss.item(), gl.item(), ll.item()])
+        cat = {k: torch.cat(v) for k, v in acc.items()}
+        gs = ref_model.sim_matrix(cat["gt"], cat["go"]).detach().cpu().numpy()
+        ls = loss_fn.local_loss.get_sim_by_segment(cat["lo"], cat["lt"], cat["om"], cat["len"], cat["tm"], device="cpu")
+    o2t = gs + ls
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    out = dict(F=F, R=R, batch=BS, batches=NB, val_losses=np.array(val, np.float64), global_sims=gs, local_sims=ls, o2t_sims=o2t)
+    for name, fn in (("t2v", rm.t2v_metrics), ("v2t", rm.v2t_metrics)):
+        r = fn(o2t)
+        out[name] = np.array([r[k] for k in keys], np.float64)
+        print("g9", name, {k: round(float(r[k]), 3) for k in keys})
+    np.savez_compressed(os.path.join(HERE, "g9_eval.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref_model, ref_loss, ref_data, scratch = import_reference()
+    only = set(sys.argv[1:])          # e.g. `make_golden.py g8 g9`: regenerate just those files
+    if only:
+        if "g4" in only:
+            golden_xattn(ref_loss)
+        if "timeattn" in only:
+            golden_model(ref_model, ref_loss, ref_data, scratch, F=4, R=12, B=2, tag="F4_R12_B2_timeattn", time_module="timeattn")
+        if "g8" in only:
+            golden_loss_curve(ref_model, ref_loss, ref_data, scratch)
+        if "g9" in only:
+            golden_eval(ref_model, ref_loss, ref_data, scratch)
+        return
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
     golden_metrics(ref_loss)
@@ -279,6 +427,9 @@ def main():
     golden_model(ref_model, ref_loss, ref_data, scratch, F=8, R=30, B=3, tag="F8_R30_B3")
     golden_model(ref_model, ref_loss, ref_data, scratch, F=1, R=30, B=4, tag="F1_R30_B4")
     golden_model(ref_model, ref_loss, ref_data, scratch, F=32, R=36, B=2, tag="F32_R36_B2", with_grads=False)
+    golden_model(ref_model, ref_loss, ref_data, scratch, F=4, R=12, B=2, tag="F4_R12_B2_timeattn", time_module="timeattn")
+    golden_loss_curve(ref_model, ref_loss, ref_data, scratch)
+    golden_eval(ref_model, ref_loss, ref_data, scratch)
 
 
 if __name__ == "__main__":

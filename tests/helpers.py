@@ -36,6 +36,17 @@ def golden_batch(F, R, B):
     return np.stack(objs), np.stack(masks), ids, att
 
 
+def eval_batch(F, R, B, first):
+    """Batch `first // B` of the G9 eval set (make_golden.py:golden_eval): samples first .. first+B-1."""
+    objs, masks = [], []
+    for s in range(first, first + B):
+        o, m, _, _ = oracle_clip(s, F, R)
+        objs.append(o)
+        masks.append(m)
+    ids, att = syn.caption_batch(B, first_sample=first)
+    return np.stack(objs), np.stack(masks), ids, att
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)

@@ -112,6 +112,21 @@ def _dp_worker(rank, world, port, q):
     (g * w).sum().backward()
     ok_gather = torch.equal(g.detach()[3 * rank:3 * rank + 3], x.detach()) and g.shape == (3 * world, 2) \
         and torch.equal(x.grad, w[3 * rank:3 * rank + 3])
+    # gather_embeddings (the opt-in cross-GPU negatives): every rank sees all ranks' embeddings in rank order, masks / lengths
+    # are gathered without gradient, and the backward of each embedding is this rank's slice (no reduce-scatter)
+    from demovlp_amd.trainer import gather_embeddings
+    emb = {k: (torch.randn(3, *shape) + 10 * rank).requires_grad_(True) for k, shape in
+           (("global_text_embeddings", (4,)), ("local_text_embeddings", (5, 4)), ("global_object_embeddings", (4,)), ("local_object_embeddings", (6, 4)))}
+    emb["object_mask"] = torch.full((3, 6), float(rank))
+    gout, glen, gmask = gather_embeddings(emb, torch.full((3,), rank + 7), torch.full((3, 5), -100.0 * rank), args)
+    ok_gather &= all(gout[k].shape[0] == 3 * world and torch.equal(gout[k][3 * rank:3 * rank + 3].detach(), emb[k].detach()) for k in emb)
+    ok_gather &= glen.tolist() == [7] * 3 + [8] * 3 and gmask.shape == (6, 5) and float(gmask[3:].max()) == -100.0
+    ok_gather &= float(gout["object_mask"][3:].min()) == 1.0 and not gout["object_mask"].requires_grad
+    tot = sum((gout[k] * (1.0 + torch.arange(gout[k].shape[0], dtype=torch.float32).reshape(-1, *[1] * (gout[k].dim() - 1)))).sum()
+              for k in emb if k != "object_mask")
+    tot.backward()
+    ok_gather &= all(torch.equal(emb[k].grad, (1.0 + torch.arange(3 * rank, 3 * rank + 3, dtype=torch.float32)).reshape(-1, *[1] * (emb[k].dim() - 1)).expand_as(emb[k]))
+                     for k in emb if k != "object_mask")
     # GradReducer over a flat arena: bucketed in-place all-reduce, never-used tensors excluded
     torch.manual_seed(0)
     from demovlp_amd.functional import _grad_buf
@@ -235,3 +250,48 @@ def test_frame_sampling_and_npz_schema(tmp_path):
     x, bbox, conf, wh = read_frame_npz(str(tmp_path / "2.npz"))
     assert np.array_equal(x, fr["x"]) and np.array_equal(bbox, fr["bbox"]) and np.array_equal(conf, fr["objects_conf"]) and wh == (640.0, 360.0)
     assert list(alternate([[1, 2, 3], ["a", "b"]])) == [(0, 1), (1, "a"), (0, 2), (1, "b")]
+
+
+def test_adjust_learning_rate_reproduces_the_reference_quirk():
+    """trainer/trainer_dist.py:97-102: lr := learning_rate1 x 0.1 per passed milestone, whatever the config's lr was."""
+    from demovlp_amd.trainer import adjust_learning_rate
+
+    class Opt:
+        param_groups = [{"lr": 1e-5}, {"lr": 3e-5}]
+
+    class Args:
+        learning_rate1, schedule = 2e-4, [3, 6]
+    for epoch, want in ((1, 2e-4), (2, 2e-4), (3, 2e-5), (5, 2e-5), (6, 2e-6), (9, 2e-6)):
+        assert abs(adjust_learning_rate(Opt, epoch, Args) - want) < 1e-18
+        assert all(abs(g["lr"] - want) < 1e-18 for g in Opt.param_groups)
+
+
+def test_fused_adamw_state_dict_uses_the_reference_checkpoint_layout():
+    """base/base_trainer.py:185-192 stores transformers.AdamW.state_dict(): {'state': {i: {step, exp_avg, exp_avg_sq}},
+    'param_groups': [{..., 'params': [0..n-1]}]}, i = position among the trainable parameters in model.parameters() order --
+    not the arena's (matrices first) order -- and no entry for tensors that never had a gradient."""
+    from demovlp_amd.trainer import FusedAdamW, ParamArena
+    net = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.LayerNorm(4), torch.nn.Linear(4, 2))
+    order = [n for n, _ in net.named_parameters()]                  # 0.weight 0.bias 1.weight 1.bias 2.weight 2.bias
+    arena = ParamArena(net, device="cpu")
+    assert [arena.names[i] for i in arena.model_order] == order and arena.names[:2] == ["0.weight", "2.weight"]
+    opt = FusedAdamW(arena, lr=3e-4)
+    opt.step_count = 5
+    touched = [i for i, n in enumerate(arena.names) if n != "1.bias"]
+    opt._ever = set(touched)
+    for i in touched:
+        lo, hi = arena.slice_of(i)
+        opt.m[lo:hi] = float(i + 1)
+        opt.v[lo:hi] = float(10 * (i + 1))
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == [0, 1, 2, 4, 5] and sd["param_groups"][0]["params"] == list(range(6))
+    assert sd["param_groups"][0]["lr"] == 3e-4 and sd["param_groups"][0]["betas"] == (0.9, 0.999) and sd["param_groups"][0]["correct_bias"] is True
+    for k, st in sd["state"].items():
+        i = arena.names.index(order[k])
+        assert st["step"] == 5 and st["exp_avg"].shape == arena.params[i].shape
+        assert float(st["exp_avg"].mean()) == i + 1 and float(st["exp_avg_sq"].mean()) == 10 * (i + 1)
+    net2 = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.LayerNorm(4), torch.nn.Linear(4, 2))
+    opt2 = FusedAdamW(ParamArena(net2, device="cpu"), lr=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 5 and opt2.param_groups[0]["lr"] == 3e-4 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    assert opt2._ever == opt._ever

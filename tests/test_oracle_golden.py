@@ -6,7 +6,7 @@ import torch
 
 from demovlp_amd import synthetic as syn
 from oracle import restatement as orc
-from helpers import load_golden, oracle_clip, golden_batch, rel_err, n_raw_for
+from helpers import load_golden, oracle_clip, golden_batch, rel_err, n_raw_for, eval_batch
 
 TOL = 1e-4   # north_star: within 1e-4 fp32 (relative to max(1, |ref|_inf))
 
@@ -61,13 +61,13 @@ def test_sim_matrix_norm_softmax():
 
 
 @pytest.mark.parametrize("tag,with_grads", [("F8_R36_B2", True), ("F8_R30_B3", True), ("F1_R30_B4", True),
-                                            ("F32_R36_B2", False)])
+                                            ("F32_R36_B2", False), ("F4_R12_B2_timeattn", True)])
 def test_model_forward_backward(tag, with_grads):
     g = load_golden(f"g2_model_{tag}.npz")
     F, R, B = int(g["F"]), int(g["R"]), int(g["B"])
     obj, mask, ids, att = golden_batch(F, R, B)
     torch.set_num_threads(8)
-    p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=with_grads)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R, "timeattn" if tag.endswith("timeattn") else None), requires_grad=with_grads)
     obj_t, mask_t = torch.from_numpy(obj), torch.from_numpy(mask).float()
     ids_t, att_t = torch.from_numpy(ids), torch.from_numpy(att)
     ttaps, otaps = {}, {}
@@ -125,3 +125,70 @@ def test_eval_grid_scores_match_reference_get_sim_by_segment():
     got = orc.xattn_scores_batched(torch.from_numpy(im), torch.from_numpy(cap), torch.from_numpy(m_img), torch.from_numpy(m_cap), 20.0, True)
     assert rel_err(got.numpy(), g["grid_sims"]) < 1e-4
 
+
+
+def test_focal_gate_margins_recorded():
+    """the focal gate H = [P L - sum P > 0] is a hard threshold; the goldens record how close the fixtures'
+    probabilities sit to it.  No element is within fp32 resolution of the threshold, so a gate flip is never a legitimate
+    excuse for a score difference on these fixtures (the 1e-4 bar above stands without exceptions)."""
+    g = load_golden("g4_losses.npz")
+    hist, edges = g["gate_margin_hist"], g["gate_margin_edges"]
+    assert hist.sum() > 1e7 and float(g["gate_margin_min"][0]) > 5e-7
+    assert hist[edges[:-1] < 1e-7].sum() == 0
+
+
+@pytest.mark.parametrize("tag,lr", [("lr1e-5", 1e-5), ("lr2e-4", 2e-4)])
+def test_ten_step_loss_curve_vs_reference(tag, lr):
+    """G8: 10 optimisation steps of the imported reference (+ HF-AdamW restated in make_golden.py) against the oracle's
+    train_step + hf_adamw_step on the same batch: total / global / local loss within 1e-3 at every step."""
+    g = load_golden("g8_loss_curve.npz")
+    F, R, B = 8, 36, 2
+    obj, mask, ids, att = golden_batch(F, R, B)
+    torch.set_num_threads(8)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=True)
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()}
+    args = (torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask).float())
+    for step in range(1, 11):
+        for v in p.values():
+            v.grad = None
+        got = orc.train_step(p, *args)
+        ref = g[tag][step - 1]
+        assert np.abs(np.array([x.item() for x in got]) - ref).max() < 1e-3 * max(1.0, abs(ref[0])), (step, got, ref)
+        with torch.no_grad():
+            for k, v in p.items():
+                if v.grad is not None:
+                    orc.hf_adamw_step(v, v.grad, st[k][0], st[k][1], step, lr=lr)
+    if tag == "lr2e-4":
+        assert rel_err(st["txt_proj.1.weight"][0].numpy(), g["opt_txt_proj_exp_avg"]) < 1e-3
+        assert rel_err(p["txt_proj.1.weight"].detach().numpy(), g["opt_txt_proj_weight"]) < 1e-3
+
+
+def test_eval_pipeline_vs_reference():
+    """G9: embeddings of 96 MSRVTT-shape pairs (F=8, R=30) -> sim_matrix + transposed local grid -> retrieval metrics, exactly as
+    trainer/trainer_dist.py:358-399 composes them."""
+    from demovlp_amd import metric
+    g = load_golden("g9_eval.npz")
+    F, R, BS, NB = int(g["F"]), int(g["R"]), int(g["batch"]), int(g["batches"])
+    torch.set_num_threads(8)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R))
+    acc = {k: [] for k in ("gt", "go", "lt", "lo", "om", "tm")}
+    with torch.no_grad():
+        for b in range(NB):
+            obj, mask, ids, att = eval_batch(F, R, BS, b * BS)
+            out = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask).float())
+            tm = (torch.from_numpy(att)[:, 1:].float() - 1.0) * 100.0
+            for k, v in zip(acc, (out["global_text_embeddings"], out["global_object_embeddings"], out["local_text_embeddings"],
+                                  out["local_object_embeddings"], out["object_mask"], tm)):
+                acc[k].append(v)
+            loss, gl, ll, _, _ = orc.global_local_loss(out, tm)
+            assert np.abs(np.array([loss.item(), gl.item(), ll.item()]) - g["val_losses"][b]).max() < 1e-4 * max(1.0, g["val_losses"][b][0])
+        cat = {k: torch.cat(v) for k, v in acc.items()}
+        gs = orc.sim_matrix(cat["gt"], cat["go"]).numpy()
+        ls = orc.xattn_scores_batched(cat["lo"], cat["lt"], cat["om"].float(), cat["tm"]).numpy()
+    assert rel_err(gs, g["global_sims"]) < 1e-4 and rel_err(ls, g["local_sims"]) < 1e-4
+    o2t = gs + ls                                   # [text, video] + [video, text]: the reference's own orientation mix
+    assert rel_err(o2t, g["o2t_sims"]) < 1e-4
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
+        r = fn(g["o2t_sims"])
+        assert np.allclose([r[k] for k in keys], g[name], rtol=1e-9, atol=1e-9), name
