@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--p8", type=int, default=-1, help="override dvlp_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
     ap.add_argument("--no-object-tower", action="store_true", help="skip the object-transformer-only fwd+bwd timing")
+    ap.add_argument("--parallel-towers", type=int, default=0, help="1: text tower on its own HIP stream, concurrent with the object tower")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
                          "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
@@ -204,7 +205,8 @@ def main():
     gather = None
     if a.gather_negatives and (world > 1 or force_dist):
         gather = argparse.Namespace(world_size=world, rank=rank)
-    use_graph = bool(a.graph) and gather is None and not a.overlap_wgrad
+    use_graph = bool(a.graph) and gather is None
+    model.parallel_towers = bool(a.parallel_towers)
     reducer, stepper = None, None
     if use_graph:
         stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist)

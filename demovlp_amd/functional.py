@@ -93,9 +93,16 @@ class _Side:
 
 
 def join_side_stream():
-    """Make the current stream wait for all side-stream gradient work (call before gradients are consumed)."""
-    if OVERLAP_WGRAD and torch.cuda.is_available():
-        torch.cuda.current_stream().wait_stream(ops.side_stream())
+    """Make the current stream wait for all side-stream work: gradient kernels on the side stream, and the text tower's
+    stream when the towers run concurrently (call before gradients are consumed)."""
+    if not torch.cuda.is_available():
+        return
+    cur = torch.cuda.current_stream()
+    if OVERLAP_WGRAD:
+        cur.wait_stream(ops.side_stream())
+    dev = torch.cuda.current_device()
+    if dev in ops._TEXT and ops._TEXT[dev] != cur:
+        cur.wait_stream(ops._TEXT[dev])
 
 
 def _wgrad(dy2d, x2d, param):

@@ -66,6 +66,9 @@ class ObjectRelation(nn.Module):
                 self.load_state_dict_with_mismatch(new_state_dict)
         self.segments = object_params["num_frames"]
         self.projection_dim = 256
+        # the two towers are independent until the loss: run the text tower on its own HIP stream so that its under-filled
+        # launches (M = batch x 100 tokens) share the chip with the object tower's (default off: per-kernel timings stay clean)
+        self.parallel_towers = False
 
     # ---- knobs that do not exist in the reference -------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -80,8 +83,20 @@ class ObjectRelation(nn.Module):
 
     def forward(self, data, return_embeds=True):
         text_data = data["text"]
-        gt, lt = self.compute_text(text_data)
-        go, lo, object_mask = self.compute_object(data["object"], data["object_mask"])
+        if self.parallel_towers and text_data["input_ids"].is_cuda:
+            from . import ops
+            main = torch.cuda.current_stream()
+            ts = ops.text_stream()
+            ts.wait_stream(main)
+            with torch.cuda.stream(ts):
+                gt, lt = self.compute_text(text_data)
+            go, lo, object_mask = self.compute_object(data["object"], data["object_mask"])
+            main.wait_stream(ts)
+            gt.record_stream(main)
+            lt.record_stream(main)
+        else:
+            gt, lt = self.compute_text(text_data)
+            go, lo, object_mask = self.compute_object(data["object"], data["object_mask"])
         return dict(global_text_embeddings=gt.contiguous(), local_text_embeddings=lt.contiguous(),
                     global_object_embeddings=go.contiguous(), local_object_embeddings=lo.contiguous(),
                     object_mask=object_mask[:, 1:, ...].contiguous())

@@ -86,6 +86,17 @@ def side_stream(device=None):
     return _SIDE[device]
 
 
+_TEXT = {}
+
+
+def text_stream(device=None):
+    """HIP stream the text tower runs on when the two towers run concurrently (model.ObjectRelation.parallel_towers)."""
+    device = torch.cuda.current_device() if device is None else device
+    if device not in _TEXT:
+        _TEXT[device] = torch.cuda.Stream(device=device)
+    return _TEXT[device]
+
+
 def linear_fwd(x2d, w, bias=None, res=None, gelu_aux=None):
     """y = x W^T (+ bias) (+ res); with gelu_aux given: aux <- pre-activation, y <- gelu(pre)."""
     M, K = x2d.shape

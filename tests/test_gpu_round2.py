@@ -54,10 +54,10 @@ def test_sim_matrix_rectangular_forward_backward(N, M, dtype):
     if N > 2:
         a[2] = 0                                              # a zero row takes the |x| <= eps branch
     w = torch.from_numpy(rng.standard_normal((N, M), dtype=np.float32))
-    ar, br = a.float().requires_grad_(True), b.float().requires_grad_(True)
+    ar, br = a.float().clone().requires_grad_(True), b.float().clone().requires_grad_(True)
     ref = orc.sim_matrix(ar, br)
     (ref * w).sum().backward()
-    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    ad, bd = a.detach().clone().to(DEV).requires_grad_(True), b.detach().clone().to(DEV).requires_grad_(True)
     got = sim_matrix(ad, bd)
     assert got.shape == (N, M) and got.dtype == torch.float32
     (got * w.to(DEV)).sum().backward()
@@ -104,11 +104,13 @@ def test_bf16_default_arena_keeps_learning():
         Fn.SHADOWS.clear()
         model = build(F, R, "bfloat16")
         arena = ParamArena(model, bf16_shadow=shadow)
-        opt = FusedAdamW(arena, lr=1e-3)
+        opt = FusedAdamW(arena, lr=1e-5)
         data = to_dev(*golden_batch(F, R, B))
         curves.append([float(train_step(model, loss_head(), opt, data)[0].item()) for _ in range(4)])
-    assert curves[0][0] - curves[0][3] > 0.5                       # the loss does move at lr 1e-3
-    assert np.allclose(curves[0], curves[1], rtol=0, atol=1e-6), curves
+    assert curves[0][0] - curves[0][3] > 2.0                       # the loss does move (7.37 -> 2.9 in the reference's curve, golden G8)
+    # stale shadows would freeze the forward at the step-0 weights (a flat curve); the two arenas round differently (packed
+    # q|k|v projection only with the optimizer-written shadow), so the curves agree to bf16 noise, not bit for bit
+    assert curves[1][0] - curves[1][3] > 2.0 and np.allclose(curves[0], curves[1], rtol=3e-2, atol=0), curves
 
 
 def test_second_backward_before_step_is_refused():
@@ -161,10 +163,14 @@ def test_graph_replay_equals_eager(dtype):
 
 @pytest.mark.parametrize("tag,lr,graphed", [("lr1e-5", 1e-5, True), ("lr2e-4", 2e-4, False)])
 def test_ten_step_loss_curve_and_optimizer_state_vs_reference(tag, lr, graphed, tmp_path):
-    """Golden G8: 10 optimisation steps of the imported reference (HF-AdamW) -- fp32 HIP path within 1e-3 at every step, through
-    the graph-replayed step at the config's lr and the eager one at the lr the reference's _adjust_learning_rate switches to.
+    """Golden G8: 10 optimisation steps of the imported reference (HF-AdamW), through the graph-replayed step at the config's lr
+    and the eager one at the lr the reference's _adjust_learning_rate switches to.  Tolerances: 1e-3 against the exact-arithmetic
+    (fp64 oracle) curve G8b at every step; 3e-3 against the reference's own fp32 curve, which itself sits up to 2.3e-3 off G8b
+    (Adam turns rounding noise on near-zero gradients into +-lr moves and the RWA tail amplifies score noise ~70x: see
+    tests/golden/make_f64_curve.py) -- its first four steps, before that noise has grown, agree to 2e-4.
     Then the optimizer state_dict in the reference's layout: same keys, same first moment, and a save / resume round trip."""
     g = load_golden("g8_loss_curve.npz")
+    g64 = load_golden("g8b_loss_curve_f64.npz")
     F, R, B = 8, 36, 2
     model = build(F, R)
     arena = ParamArena(model)
@@ -175,10 +181,17 @@ def test_ten_step_loss_curve_and_optimizer_state_vs_reference(tag, lr, graphed, 
     lf = loss_head()
     data = to_dev(*golden_batch(F, R, B))
     stepper = GraphedTrainStep(model, lf, opt, warmup=2) if graphed else None
+    curve = []
     for step in range(10):
         out = stepper(data) if graphed else train_step(model, lf, opt, data)
-        got = np.array([float(x.item()) for x in out])
-        assert np.abs(got - g[tag][step]).max() < 1e-3 * max(1.0, abs(g[tag][step][0])), (step, got, g[tag][step])
+        curve.append([float(x.item()) for x in out])
+    curve = np.array(curve)
+    dev = np.abs(curve - g[tag]) / np.maximum(1.0, np.abs(g[tag][:, :1]))
+    dev64 = np.abs(curve - g64[tag]) / np.maximum(1.0, np.abs(g64[tag][:, :1]))
+    print("\nG8", tag, "relative deviation per step vs the reference (fp32):", np.array2string(dev.max(axis=1), precision=5))
+    print("G8b", tag, "relative deviation per step vs the fp64 oracle    :", np.array2string(dev64.max(axis=1), precision=5))
+    assert dev64.max() < 1e-3, (tag, dev64.max(axis=1))
+    assert dev[:4].max() < 2e-4 and dev.max() < 3e-3, (tag, dev.max(axis=1))
     if tag != "lr2e-4":
         return
     sd = opt.state_dict()
