@@ -228,3 +228,35 @@ extern "C" int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* sr
     else return DVLP_ERR_DTYPE;
     return dvlp_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Token-grid transpose for the time attention of SpaceTimeBlock (model/object_transformer.py:252-258: einops
+// 'b (f n) d -> (b n) f d'): dst[b][0] = src[b][0], dst[b][1 + n F + f] = src[b][1 + f R + n]  (+ res at the destination
+// index when given).  Time attention over (F frames x R regions) is then exactly the space-attention kernel run on the
+// transposed token order with the roles (frames, regions) = (R, F); calling this again with F and R swapped goes back.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void token_transpose_kernel(int N, int F, int R, int D, const T* __restrict__ src, const T* __restrict__ res,
+                                                              T* __restrict__ dst) {
+    const int64_t row = blockIdx.x;                 // destination row b * N + t
+    const int t = (int)(row % N);
+    const int64_t b = row / N;
+    int s = 0;
+    if (t > 0) { const int n = (t - 1) / F, f = (t - 1) % F; s = 1 + f * R + n; }
+    const T* sp = src + (b * N + s) * D;
+    const T* rp = res ? res + row * D : nullptr;
+    T* dp = dst + row * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dp[d] = from_f<T>(to_f(sp[d]) + (rp ? to_f(rp[d]) : 0.f));
+}
+
+extern "C" int dvlp_token_transpose(int dtype, int64_t B, int64_t F, int64_t R, int64_t D, const void* src, const void* res, void* dst, void* stream) {
+    dvlp_clear_status();
+    if (B <= 0 || F <= 0 || R <= 0 || D <= 0) return DVLP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = 1 + (int)(F * R);
+    dim3 grid((unsigned)(B * N)), block(D >= 256 ? 256 : 64);
+    if (dtype == DVLP_F32) hipLaunchKernelGGL(token_transpose_kernel<float>, grid, block, 0, st, N, (int)F, (int)R, (int)D, (const float*)src, (const float*)res, (float*)dst);
+    else if (dtype == DVLP_BF16) hipLaunchKernelGGL(token_transpose_kernel<bf16>, grid, block, 0, st, N, (int)F, (int)R, (int)D, (const bf16*)src, (const bf16*)res, (bf16*)dst);
+    else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}

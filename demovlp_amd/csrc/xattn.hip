@@ -34,6 +34,16 @@ struct XLayout {
 static size_t pair_lds(int64_t G, int64_t W, int bwd);
 static bool g_force_general = false;
 extern "C" int dvlp_xattn_force_general(int on) { g_force_general = on != 0; return DVLP_OK; }
+// fused per-pair kernels (xfused.hip): bf16, G <= 288, W <= 112
+bool dvlp_xfused_ok(int64_t G, int64_t W);
+int64_t dvlp_xfused_workspace_bytes(int64_t Bi, int64_t Bj, int64_t G, int64_t W);
+int dvlp_xfused_fwd(int64_t Bi, int64_t Bj, int64_t G, int64_t W, const void* Craw, const void* Qraw, const float* mimg, const float* mcap,
+                    float lam, int gate, float* scores, void* workspace, hipStream_t st);
+static int g_fused = 1;          // 1 (default): use the fused kernels where they apply; 0: always the multi-kernel path (A/B, tests)
+extern "C" int dvlp_xattn_fused_mode(int mode) { g_fused = mode; return DVLP_OK; }
+static bool x_fused(int dtype, int64_t G, int64_t W, int bwd) {
+    return g_fused && !g_force_general && dtype == DVLP_BF16 && !bwd && dvlp_xfused_ok(G, W);
+}
 static bool x_general(int64_t G, int64_t W) { return g_force_general || pair_lds(G, W, 1) > 160 * 1024; }
 
 static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
@@ -71,6 +81,7 @@ static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, 
 }
 
 extern "C" int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
+    if (x_fused(dtype, G, W, bwd)) return dvlp_xfused_workspace_bytes(Bi, Bj, G, W);
     return xlayout(dtype, Bi, Bj, G, W, bwd).total;
 }
 
@@ -818,6 +829,10 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     dvlp_clear_status();
     if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
+    if (x_fused(dtype, G, W, bwd)) {
+        dvlp_xfused_fwd(Bi, Bj, G, W, Craw, Qraw, mimg, mcap, lam, gate, scores, workspace, (hipStream_t)stream);
+        return dvlp_launch_status();
+    }
     const bool general = x_general(G, W);
     if (general && (W > 128 || (size_t)G * XWS * 3 * sizeof(float) > 150 * 1024)) return DVLP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

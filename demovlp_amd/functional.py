@@ -314,6 +314,68 @@ class VitBlockFn(torch.autograd.Function):
         return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None)
 
 
+class TimeSpaceBlockFn(torch.autograd.Function):
+    """SpaceTimeBlock with time_module='timeattn' (model/object_transformer.py:249-274): time attention over norm3(x) for every
+    region slot ('b (f n) d -> (b n) f d', CLS query over all tokens), space attention over norm1(x + time), and -- the
+    FrozenInTime residual -- the space output is added to the block INPUT x (:267), then the MLP.  The time attention is the
+    space-attention kernel on the token grid transposed to region-major order (ops.token_transpose) with (F, R) swapped."""
+
+    @staticmethod
+    def forward(ctx, x, addmask, addmask_t, n3w, n3b, tqw, tqb, tpw, tpb, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, F, R):
+        B, N, D = x.shape
+        cd = x.dtype
+        x2 = x.reshape(B * N, D)
+        h3, _, m3, r3 = ops.layernorm_fwd(x2, n3w.detach(), n3b.detach(), 1e-6)
+        h3t = ops.token_transpose(h3.reshape(B, N, D), B, F, R).reshape(B * N, D)
+        tqkv = ops.linear_fwd(h3t, SHADOWS.get(tqw, cd), tqb.detach())
+        tatt = ops.space_attention_fwd(tqkv, addmask_t, B, R, F)                   # frames <-> regions: time attention
+        tout = ops.linear_fwd(tatt, SHADOWS.get(tpw, cd), tpb.detach())            # region-major rows
+        xin = ops.token_transpose(tout.reshape(B, N, D), B, R, F, res=x).reshape(B * N, D)      # back to frame-major, + x
+        h1, _, m1, r1 = ops.layernorm_fwd(xin, n1w.detach(), n1b.detach(), 1e-6)
+        qkv = ops.linear_fwd(h1, SHADOWS.get(qkvw, cd), qkvb.detach())
+        att = ops.space_attention_fwd(qkv, addmask, B, F, R)
+        x1 = ops.linear_fwd(att, SHADOWS.get(pw, cd), pb.detach(), res=x2)         # residual from x, not from xin
+        h2, _, m2, r2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6)
+        pre = torch.empty((B * N, f1w.shape[0]), device=x.device, dtype=cd)
+        a = ops.linear_fwd(h2, SHADOWS.get(f1w, cd), f1b.detach(), gelu_aux=pre)
+        y = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach(), res=x1)
+        ctx.save_for_backward(x2, addmask, addmask_t, m3, r3, h3t, tqkv, tatt, xin, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a)
+        ctx.params = (n3w, n3b, tqw, tqb, tpw, tpb, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.dims = (B, N, F, R)
+        return y.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, addmask, addmask_t, m3, r3, h3t, tqkv, tatt, xin, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a = ctx.saved_tensors
+        n3w, n3b, tqw, tqb, tpw, tpb, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = ctx.params
+        B, N, F, R = ctx.dims
+        cd = x2.dtype
+        D = x2.shape[1]
+        dy2 = dy.reshape(B * N, -1).contiguous()
+        df2b = _bgrad(dy2, f2b)
+        dpre, df1b = _dx_with_bias_grad(dy2, SHADOWS.get(f2w, cd), pre, f1b)
+        dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
+        dx1, dn2w, dn2b, dpb = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2, bias_of_next=pb)
+        datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
+        dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R)
+        dqkvb = _bgrad(dqkv, qkvb)
+        dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
+        dxin, dn1w, dn1b = _ln_bwd(dh1, xin, n1w, n1b, m1, r1)                      # xin feeds norm1 only
+        dtout = ops.token_transpose(dxin.reshape(B, N, D), B, F, R).reshape(B * N, D)           # gradient of the region-major rows
+        dtpb = _bgrad(dtout, tpb)
+        dtatt = ops.linear_bwd_input(dtout, SHADOWS.get(tpw, cd))
+        dtqkv = ops.space_attention_bwd(tqkv, addmask_t, dtatt, B, R, F)
+        dtqb = _bgrad(dtqkv, tqb)
+        dh3t = ops.linear_bwd_input(dtqkv, SHADOWS.get(tqw, cd))
+        dh3 = ops.token_transpose(dh3t.reshape(B, N, D), B, R, F).reshape(B * N, D)
+        dres = ops.token_transpose(dxin.reshape(B, N, D), B, 1, N - 1, res=dx1.reshape(B, N, D)).reshape(B * N, D)   # dx1 + dxin (x feeds both residuals)
+        df2w, df1w, dpw, dqkvw, dtpw, dtqw = _wgrad_group([(dy2, a, f2w), (dpre, h2, f1w), (dx1, att, pw), (dqkv, h1, qkvw),
+                                                           (dtout, tatt, tpw), (dtqkv, h3t, tqw)])
+        dx, dn3w, dn3b = _ln_bwd(dh3, x2, n3w, n3b, m3, r3, dres=dres)
+        return (dx.reshape(B, N, -1), None, None, dn3w, dn3b, dtqw, dtqb, dtpw, dtpb, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b,
+                df1w, df1b, df2w, df2b, None, None)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # text tower (DistilBERT)
 # ----------------------------------------------------------------------------------------------------------------

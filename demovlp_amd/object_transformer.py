@@ -1,8 +1,8 @@
 """ObjectTransformer: the region-feature video encoder (mirror of model/object_transformer.py:296-452).
 
 Same constructor arguments, parameter names/shapes (state_dict interchange) and forward contract as the reference;
-the arithmetic runs in hand-written gfx950 kernels (functional.py -> ops.py -> libdemovlp_hip.so).  Only the
-configuration every shipped DemoVLP config uses is implemented: ``time_module`` falsy (space attention only).
+the arithmetic runs in hand-written gfx950 kernels (functional.py -> ops.py -> libdemovlp_hip.so).  ``time_module`` falsy
+(every shipped DemoVLP config: space attention only) and ``'timeattn'`` (:227-234, 252-258: divided space-time attention).
 """
 from __future__ import annotations
 
@@ -49,15 +49,25 @@ class SpaceTimeBlock(nn.Module):
     """model/object_transformer.py:199-274 with time_module falsy.  norm3 exists (and never gets a gradient), as in
     the reference, so checkpoints interchange."""
 
-    def __init__(self, dim=EMBED, hidden=HIDDEN):
+    def __init__(self, dim=EMBED, hidden=HIDDEN, time_module=None):
         super().__init__()
+        self.time_module = time_module
         self.norm1 = _Affine(dim)
         self.attn = VarAttention(dim)
+        if time_module == "timeattn":
+            self.timeattn = VarAttention(dim)          # time_init='rand' in the reference (:318): ordinary initialisation
         self.norm2 = _Affine(dim)
         self.mlp = Mlp(dim, hidden)
         self.norm3 = _Affine(dim)
 
-    def forward(self, x, addmask, frames, regions):
+    def forward(self, x, addmask, frames, regions, addmask_t=None):
+        if self.time_module == "timeattn":
+            t = self.timeattn
+            return Fn.TimeSpaceBlockFn.apply(x, addmask, addmask_t, self.norm3.weight, self.norm3.bias, t.qkv.weight, t.qkv.bias,
+                                             t.proj.weight, t.proj.bias, self.norm1.weight, self.norm1.bias, self.attn.qkv.weight,
+                                             self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight,
+                                             self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
+                                             self.mlp.fc2.bias, frames, regions)
         return Fn.VitBlockFn.apply(x, addmask, self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                                    self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight, self.norm2.bias,
                                    self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, frames, regions)
@@ -66,9 +76,9 @@ class SpaceTimeBlock(nn.Module):
 class ObjectTransformer(nn.Module):
     def __init__(self, input_dim=2054, region_nums=20, num_frames=4, output_dim=256, time_module=None):
         super().__init__()
-        if time_module:
-            raise NotImplementedError("time_module='timeattn' is not used by any shipped DemoVLP config and is not "
-                                      "implemented on the MI355X path (SURVEY.md section 8(f) rank 4)")
+        if time_module and time_module != "timeattn":
+            raise NotImplementedError(f"time_module={time_module!r}: the reference knows only falsy and 'timeattn'")
+        self.time_module = time_module or None
         if input_dim != 2054:
             raise NotImplementedError("region features are 2048-d + 6-d box geometry")
         self.num_frames = num_frames
@@ -78,7 +88,7 @@ class ObjectTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, EMBED))
         self.custom_pos_embed = nn.Parameter(torch.zeros(1, region_nums + 1, EMBED))
         self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, EMBED))
-        self.blocks = nn.ModuleList([SpaceTimeBlock() for _ in range(DEPTH)])
+        self.blocks = nn.ModuleList([SpaceTimeBlock(time_module=self.time_module) for _ in range(DEPTH)])
         self.norm = _Affine(EMBED)            # defined and never applied (object_transformer.py:354, 446-452)
         self.object_embedding = _Linear(self.feat_dim, EMBED)
         self.pos_embedding = _Linear(input_dim - self.feat_dim, EMBED)
@@ -98,8 +108,12 @@ class ObjectTransformer(nn.Module):
         tok, addmask = Fn.ObjectPrologueFn.apply(obj, mask01, self.object_embedding.weight, self.object_embedding.bias,
                                                  self.pos_embedding.weight, self.pos_embedding.bias, self.temporal_embed, self.cls_token,
                                                  self.custom_pos_embed, self.compute_dtype)
+        addmask_t = None
+        if self.time_module == "timeattn":
+            from . import ops
+            addmask_t = ops.token_transpose(addmask.reshape(B, 1 + F * R, 1), B, F, R).reshape(B, 1 + F * R)     # key mask in region-major order
         for blk in self.blocks:
-            tok = blk(tok, addmask, F, R)
+            tok = blk(tok, addmask, F, R, addmask_t)
         return tok, addmask
 
     def forward(self, x, x_mask):

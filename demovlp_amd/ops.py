@@ -340,6 +340,15 @@ def embed_unassemble(dx, B, F, R):
     return dtok
 
 
+def token_transpose(src, B, F, R, res=None):
+    """[B, 1 + F*R, D] frame-major tokens -> region-major ('b (f n) d -> b (n f) d', CLS in place), + ``res`` (destination
+    order) when given.  With F = 1 this is the identity, i.e. a plain ``src + res``."""
+    dst = torch.empty_like(src)
+    D = src.shape[-1]
+    call("dvlp_token_transpose", dt(src), B, F, R, D, p(src), p(res), p(dst), stream())
+    return dst
+
+
 def box_wgrad(dtok, box, out=None):
     M = dtok.shape[0]
     if out is None:

@@ -112,6 +112,10 @@ int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* bo
 int dvlp_embed_assemble(int dtype, int64_t B, int64_t F, int64_t R, const void* tok, const float* box, const float* Wp,
                         const float* bp, const float* temporal, const float* cls, const float* pos0, const float* mask01, void* x,
                         float* addmask, void* stream);
+/* time attention of SpaceTimeBlock (object_transformer.py:252-258, 'b (f n) d -> (b n) f d'): dst[b][1 + n F + f] = src[b][1 + f R + n]
+   (+ res at the destination index when non-NULL), CLS row in place; dvlp_attention_* mode 0 on the transposed order with (F, R)
+   swapped IS the time attention; the same call with F and R swapped transposes back.  F = 1 is the identity (a plain add). */
+int dvlp_token_transpose(int dtype, int64_t B, int64_t F, int64_t R, int64_t D, const void* src, const void* res, void* dst, void* stream);
 int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R, const void* dx, void* dtok, void* stream);
 int64_t dvlp_box_wgrad_chunks(int64_t M);
 int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const float* box, float* dWp, float* workspace, int accumulate,
@@ -125,6 +129,11 @@ int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* ds
 /* ---- local loss: xattn_score_fast / func_attention_fast / focal_equal / cosine_similarity (model/loss.py:209-330) ---- */
 /* testing knob: 1 = always take the general-G (long-video) softmax path, even when the fused per-pair kernels fit LDS */
 int dvlp_xattn_force_general(int on);
+/* 1 (default): bf16 pairs with F*R <= 288, W <= 112 run the fused per-pair kernels (everything between the embeddings and the
+   score on chip); 0: always the multi-kernel path -- for A/B measurements and tests */
+int dvlp_xattn_fused_mode(int mode);
+/* TIMING-ONLY ablation of the fused forward kernel (stop after phase n); 0 in production */
+int dvlp_xfused_ablate(int stop);
 int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd);
 int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                    const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd, void* stream);
