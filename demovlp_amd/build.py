@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdemovlp_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "xattn.hip", "xfused.hip", "losses.hip", "select.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "xattn.hip", "xfused.hip", "losses.hip", "select.hip", "optim.hip", "dropout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

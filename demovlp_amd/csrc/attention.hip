@@ -33,7 +33,23 @@ struct AttnArgs {
     float scale;
     int seg_begin;             // first segment index served by blockIdx.x = 0 (CLS-only launches start at nseg)
     int abl;                   // TIMING-ONLY ablation bits (tools/attn_bench.py): 0 in production
+    // attention-probability dropout (mode 1, HF MultiHeadSelfAttention: weights = dropout(softmax(scores))): keep bytes in both
+    // orientations, [b*H + h][q][key] and [b*H + h][key][q], row stride Ns; the product P V uses P keep kscale.  null = off.
+    const uint8_t *keep, *keepT;
+    float kscale;
+    int Ns;
 };
+static thread_local const uint8_t *t_keep = nullptr, *t_keepT = nullptr;
+static thread_local float t_kscale = 1.f;
+extern "C" int dvlp_attention_dropout_next(const void* keep, const void* keepT, float scale) {
+    t_keep = (const uint8_t*)keep; t_keepT = (const uint8_t*)keepT; t_kscale = scale; return DVLP_OK;
+}
+// four consecutive keep bytes as multipliers
+__device__ __forceinline__ void keep4(const uint8_t* p, float scale, float (&m)[4]) {
+    const uint32_t kb = *(const uint32_t*)p;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) m[t] = ((kb >> (8 * t)) & 1u) ? scale : 0.f;
+}
 static int g_attn_abl = 0;
 static int g_attn_merged = 1;      // space-mode bf16 backward: 1 = one-pass form, 0 = the three-launch form (A/B, tests)
 extern "C" int dvlp_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
@@ -111,9 +127,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             const float m = wave_max(fmaxf(s0, s1));
             const float e0 = lane < nk ? expf(s0 - m) : 0.f, e1 = lane + 64 < nk ? expf(s1 - m) : 0.f;
             const float inv = 1.f / wave_sum(e0 + e1);
+            float d0 = e0, d1 = e1;                                  // numerators entering P V (dropped when dropout is on)
+            if (a.keep && a.mode == 1) {
+                const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + i) * a.Ns;
+                d0 = (lane < nk && kr[lane]) ? e0 * a.kscale : 0.f;
+                d1 = (lane + 64 < nk && kr[lane + 64 < a.Ns ? lane + 64 : 0]) ? e1 * a.kscale : 0.f;
+            }
             float o = 0.f;
             for (int j = 0; j < nk; ++j) {
-                const float pj = j < 64 ? lane_bcast(e0, j) : lane_bcast(e1, j - 64);
+                const float pj = j < 64 ? lane_bcast(d0, j) : lane_bcast(d1, j - 64);
                 o += pj * Vs[j * KP + lane];
             }
             out[qrow * a.ldo + h * HD + lane] = from_f<T>(o * inv);
@@ -229,10 +251,17 @@ __global__ __launch_bounds__(256) void attn_bwd_seg_kernel(AttnArgs a) {
                 dp0 += g * Vs[j0 * KP + d];
                 dp1 += g * Vs[j1 * KP + d];
             }
+            float k0m = 1.f, k1m = 1.f;                              // dropout multipliers of this query's probabilities
+            if (a.keep && a.mode == 1) {
+                const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + (c0 + i)) * a.Ns;
+                k0m = (lane < nk && kr[lane]) ? a.kscale : 0.f;
+                k1m = (lane + 64 < nk && kr[lane + 64 < a.Ns ? lane + 64 : 0]) ? a.kscale : 0.f;
+                dp0 *= k0m; dp1 *= k1m;                              // d softmax = keep scale * d(dropped weights)
+            }
             const float Dsum = wave_sum(p0 * dp0 + p1 * dp1);
             const float ds0 = p0 * (dp0 - Dsum), ds1 = p1 * (dp1 - Dsum);
-            if (lane < nk) { Ps[i * nkp + lane] = p0; dSs[i * nkp + lane] = ds0; }
-            if (lane + 64 < nk) { Ps[i * nkp + lane + 64] = p1; dSs[i * nkp + lane + 64] = ds1; }
+            if (lane < nk) { Ps[i * nkp + lane] = p0 * k0m; dSs[i * nkp + lane] = ds0; }       // dV takes the DROPPED weights
+            if (lane + 64 < nk) { Ps[i * nkp + lane + 64] = p1 * k1m; dSs[i * nkp + lane + 64] = ds1; }
             float g = 0.f;
             for (int j = 0; j < nk; ++j) {
                 const float dsj = j < 64 ? lane_bcast(ds0, j) : lane_bcast(ds1, j - 64);
@@ -536,6 +565,18 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[kt][qt][r] *= inv;
+        if (a.keep && a.mode == 1) {                                 // weights = dropout(softmax(scores)) before the context product
+            int qi = sg.qbase + 16 * qt + c;
+            qi = qi < a.N ? qi : a.N - 1;
+            const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                float m4[4];
+                keep4(kr + 16 * kt + 4 * g, a.kscale, m4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][qt][r] *= m4[r];
+            }
+        }
     }
     f32x4 o[NQT][4];
 #pragma unroll
@@ -1043,6 +1084,18 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); sum += st[kt][r]; }
         sum = col4_sum(sum);
         const float inv = 1.f / sum;
+        if (a.keep) {                                                // d softmax = keep scale * d(dropped weights)
+            int qi = 16 * qt + c;
+            qi = qi < a.N ? qi : a.N - 1;
+            const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                float m4[4];
+                keep4(kr + 16 * kt + 4 * g, a.kscale, m4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[kt][r] *= m4[r];
+            }
+        }
         float D = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -1093,6 +1146,17 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Gs, qt, 0), v0, zero4, 0, 0, 0);
             dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Gs, qt, 1), v1, acc, 0, 0, 0);
         }
+        float km[NT][4];
+        {
+            int kk = 16 * kt + c;
+            kk = kk < a.N ? kk : a.N - 1;
+            const uint8_t* kr = a.keepT ? a.keepT + (((int64_t)b * a.H + h) * a.Ns + kk) * a.Ns : nullptr;
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                if (kr) keep4(kr + 16 * qt + 4 * g, a.kscale, km[qt]);
+                else { km[qt][0] = 1.f; km[qt][1] = 1.f; km[qt][2] = 1.f; km[qt][3] = 1.f; }
+            }
+        }
         // row statistics of query q = 16 qt + 4 g + r (over ALL keys) come from layout 1 through LDS
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt)
@@ -1103,7 +1167,8 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
                 const float* sp = stats + qi * 3;
                 const float p = qok ? __expf(s2[qt][r] * a.scale + mk - sp[0]) * sp[1] : 0.f;
                 s2[qt][r] = p;                                   // P[q][key]
-                dp[qt][r] = p * (dp[qt][r] - sp[2]);             // dS[q][key]
+                dp[qt][r] = p * (dp[qt][r] * km[qt][r] - sp[2]); // dS[q][key]   (km: dropout multiplier, 1 when off)
+                s2[qt][r] *= km[qt][r];                          // dV takes the dropped weights
             }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -1152,6 +1217,8 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
     a.abl = g_attn_abl;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.out = out; a.ldo = ldo;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
+    a.keep = mode == 1 ? t_keep : nullptr; a.keepT = mode == 1 ? t_keepT : nullptr; a.kscale = t_kscale; a.Ns = (int)((N + 15) / 16 * 16);
+    t_keep = nullptr; t_keepT = nullptr; t_kscale = 1.f;
     if (int rc = attn_check(a)) return rc;
     const int nseg = mode == 0 ? (int)F : 1, nk = (int)R + (mode == 0 ? 1 : 0);
     size_t lds = (size_t)(2 * nk * KP + KMAX) * sizeof(float);
@@ -1202,6 +1269,8 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.dout = dout; a.ldo = ldo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd;
     a.ws = workspace;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
+    a.keep = mode == 1 ? t_keep : nullptr; a.keepT = mode == 1 ? t_keepT : nullptr; a.kscale = t_kscale; a.Ns = (int)((N + 15) / 16 * 16);
+    t_keep = nullptr; t_keepT = nullptr; t_kscale = 1.f;
     if (int rc = attn_check(a)) return rc;
     if (mode == 0 && !workspace) return DVLP_ERR_SHAPE;
     const int nseg = mode == 0 ? (int)F : 1, nk = (int)R + (mode == 0 ? 1 : 0);

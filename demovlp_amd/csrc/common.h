@@ -120,6 +120,20 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
     return fmaf(x * 0.39894228040143267794f, E, Phi);
 }
 
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so a dropout mask is a
+// pure function of (seed, step offset, site, element index) -- reproducible on the host (oracle/restatement.py:philox4x32_10,
+// pinned by the published known-answer vectors) and independent of launch geometry.
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 // hipGetLastError() is sticky per thread and also reports errors left behind by OTHER libraries' benign failed calls
 // (e.g. a failed attribute query inside the framework), so judge a launch by the error state it changes: clear before
 // launching (dvlp_clear_status) and read after (dvlp_launch_status).

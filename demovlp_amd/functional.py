@@ -383,18 +383,25 @@ class TextEmbedFn(torch.autograd.Function):
     """word + position embeddings -> LayerNorm(eps 1e-12).  padding_idx 0 receives no gradient."""
 
     @staticmethod
-    def forward(ctx, ids, word, pos, lnw, lnb, cd):
+    def forward(ctx, ids, word, pos, lnw, lnb, cd, drop=None):
+        """``drop``: None or (p, state, site): HF Embeddings' dropout after the LayerNorm (train mode)."""
         e, y, mean, rstd = ops.text_embed_fwd(ids, word.detach(), pos.detach(), lnw.detach(), lnb.detach(), 1e-12, cd)
-        ctx.save_for_backward(ids, e, mean, rstd)
+        keep = None
+        if drop is not None:
+            y, keep = ops.dropout_fwd(y, drop[0], drop[1], drop[2])
+        ctx.save_for_backward(ids, e, mean, rstd, keep)
         ctx.params = (word, pos, lnw, lnb)
+        ctx.drop_p = drop[0] if drop is not None else 0.0
         return y.reshape(ids.shape[0], ids.shape[1], 768)
 
     @staticmethod
     def backward(ctx, dy):
-        ids, e, mean, rstd = ctx.saved_tensors
+        ids, e, mean, rstd, keep = ctx.saved_tensors
         word, pos, lnw, lnb = ctx.params
         B, L = ids.shape
         dy2 = dy.reshape(B * L, 768).contiguous()
+        if keep is not None:
+            dy2 = ops.dropout_bwd(dy2, keep, ctx.drop_p)
         de, dg, db = _ln_bwd(dy2, e, lnw, lnb, mean, rstd)
         gv = _grad_buf(word)
         if gv is not None:
@@ -405,35 +412,47 @@ class TextEmbedFn(torch.autograd.Function):
             dword = ops.text_embed_bwd(ids, de, word.shape[0])
         dpos = torch.zeros_like(pos)
         dpos[:L] = ops.colsum_grouped(de, B, 768, L * 768, B, 0, L, 768)          # sum over the batch per position
-        return None, dword, _into(pos, dpos), dg, db, None
+        return None, dword, _into(pos, dpos), dg, db, None, None
 
 
 class BertLayerFn(torch.autograd.Function):
     """One DistilBERT TransformerBlock (post-LN, eps 1e-12, exact GELU).  ``want_relu``: also return relu(y)."""
 
     @staticmethod
-    def forward(ctx, x, addmask, qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b, want_relu):
+    def forward(ctx, x, addmask, qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b, want_relu, drop=None):
+        """``drop``: None or (p_attention, p_hidden, state, site): HF's train-mode dropouts of this block -- on the attention
+        probabilities (site) and on the feed-forward output before its residual (site + 1)."""
         B, L, D = x.shape
         cd = x.dtype
         x2 = x.reshape(B * L, D)
+        akeep = None
+        if drop is not None and drop[0] > 0.0:
+            akeep = ops.attn_keep_masks(B, L, drop[0], drop[2], drop[3], x.device)
         fused = _fused_qkv(qw, qb, kw, kb, vw, vb, cd)
         if fused is not None:
             qkv = ops.linear_fwd(x2, fused[0], fused[1])                          # [B*L, 2304] = q | k | v
             q, k, v = qkv[:, :768], qkv[:, 768:1536], qkv[:, 1536:]
-            att = ops.full_attention_fwd(q, k, v, addmask, B, L, ld=2304)
+            att = ops.full_attention_fwd(q, k, v, addmask, B, L, ld=2304, keep=akeep)
         else:
             q = ops.linear_fwd(x2, SHADOWS.get(qw, cd), qb.detach())
             k = ops.linear_fwd(x2, SHADOWS.get(kw, cd), kb.detach())
             v = ops.linear_fwd(x2, SHADOWS.get(vw, cd), vb.detach())
-            att = ops.full_attention_fwd(q, k, v, addmask, B, L)
+            att = ops.full_attention_fwd(q, k, v, addmask, B, L, keep=akeep)
         ctx.fused = fused is not None
         s1 = ops.linear_fwd(att, SHADOWS.get(ow, cd), ob.detach(), res=x2)
         x1, _, m1, r1 = ops.layernorm_fwd(s1, l1w.detach(), l1b.detach(), 1e-12)
         pre = torch.empty((B * L, f1w.shape[0]), device=x.device, dtype=cd)
         a = ops.linear_fwd(x1, SHADOWS.get(f1w, cd), f1b.detach(), gelu_aux=pre)
-        s2 = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach(), res=x1)
+        fkeep = None
+        if drop is not None and drop[1] > 0.0:
+            f = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach())
+            s2, fkeep = ops.dropout_fwd(f, drop[1], drop[2], drop[3] + 1, res=x1)     # dropout(lin2(.)) + residual
+        else:
+            s2 = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach(), res=x1)
         y, yr, m2, r2 = ops.layernorm_fwd(s2, l2w.detach(), l2b.detach(), 1e-12, want_relu=want_relu)
-        ctx.save_for_backward(x2, addmask, q, k, v, att, s1, m1, r1, x1, pre, a, s2, m2, r2)
+        ctx.save_for_backward(x2, addmask, q, k, v, att, s1, m1, r1, x1, pre, a, s2, m2, r2, fkeep,
+                              *(akeep[:2] if akeep is not None else (None, None)))
+        ctx.drop = (drop[0], drop[1]) if drop is not None else (0.0, 0.0)
         ctx.params = (qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b)
         ctx.dims = (B, L)
         y = y.reshape(B, L, D)
@@ -445,13 +464,20 @@ class BertLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dyr):
-        x2, addmask, q, k, v, att, s1, m1, r1, x1, pre, a, s2, m2, r2 = ctx.saved_tensors
+        x2, addmask, q, k, v, att, s1, m1, r1, x1, pre, a, s2, m2, r2, fkeep, akeep, akeepT = ctx.saved_tensors
         qw, qb, kw, kb, vw, vb, ow, ob, l1w, l1b, f1w, f1b, f2w, f2b, l2w, l2b = ctx.params
         B, L = ctx.dims
         cd = x2.dtype
         dy2 = dy.reshape(B * L, -1).contiguous()
-        ds2, dl2w, dl2b, df2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2, bias_of_next=f2b)
-        dpre, df1b = _dx_with_bias_grad(ds2, SHADOWS.get(f2w, cd), pre, f1b)
+        keep = (akeep, akeepT, 1.0 / (1.0 - ctx.drop[0])) if akeep is not None else None
+        if fkeep is not None:
+            ds2, dl2w, dl2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2)
+            dff = ops.dropout_bwd(ds2, fkeep, ctx.drop[1])          # gradient of lin2's output: through the dropout mask
+            df2b = _bgrad(dff, f2b)
+        else:
+            ds2, dl2w, dl2b, df2b = _ln_bwd(dy2, s2, l2w, l2b, m2, r2, bias_of_next=f2b)
+            dff = ds2
+        dpre, df1b = _dx_with_bias_grad(dff, SHADOWS.get(f2w, cd), pre, f1b)
         dx1 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd), res=ds2)
         ds1, dl1w, dl1b, dob = _ln_bwd(dx1, s1, l1w, l1b, m1, r1, bias_of_next=ob)
         datt = ops.linear_bwd_input(ds1, SHADOWS.get(ow, cd))
@@ -459,20 +485,20 @@ class BertLayerFn(torch.autograd.Function):
         if fused is not None:
             W, _, gW, gb = fused
             dqkv = torch.empty((B * L, 2304), device=q.device, dtype=cd)
-            ops.full_attention_bwd(q, k, v, addmask, datt, B, L, ld=2304, out=(dqkv[:, :768], dqkv[:, 768:1536], dqkv[:, 1536:]), ld_out=2304)
+            ops.full_attention_bwd(q, k, v, addmask, datt, B, L, ld=2304, out=(dqkv[:, :768], dqkv[:, 768:1536], dqkv[:, 1536:]), ld_out=2304, keep=keep)
             with _Side(dqkv):
                 ops.colsum(dqkv, out=gb, defer=True)
-            df2w, df1w, dow, _ = _wgrad_group([(ds2, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dqkv, x2, gW)])
+            df2w, df1w, dow, _ = _wgrad_group([(dff, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dqkv, x2, gW)])
             dqw, dkw, dvw, dqb, dkb, dvb = (_grad_buf(t) for t in (qw, kw, vw, qb, kb, vb))      # slices of the fused gradients
             dx = ops.linear_bwd_input(dqkv, W, res=ds1)
         else:
-            dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, datt, B, L)
+            dq, dk, dv = ops.full_attention_bwd(q, k, v, addmask, datt, B, L, keep=keep)
             dqb, dkb, dvb = _bgrad(dq, qb), _bgrad(dk, kb), _bgrad(dv, vb)
-            df2w, df1w, dow, dqw, dkw, dvw = _wgrad_group([(ds2, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dq, x2, qw), (dk, x2, kw), (dv, x2, vw)])
+            df2w, df1w, dow, dqw, dkw, dvw = _wgrad_group([(dff, a, f2w), (dpre, x1, f1w), (ds1, att, ow), (dq, x2, qw), (dk, x2, kw), (dv, x2, vw)])
             dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
             ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
             ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)
-        return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, dl1w, dl1b, df1w, df1b, df2w, df2b, dl2w, dl2b, None)
+        return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, dl1w, dl1b, df1w, df1b, df2w, df2b, dl2w, dl2b, None, None)
 
 
 # ----------------------------------------------------------------------------------------------------------------

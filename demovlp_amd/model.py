@@ -77,6 +77,11 @@ class ObjectRelation(nn.Module):
         self.object_model.compute_dtype = self.compute_dtype
         return self
 
+    def set_text_dropout(self, dropout, attention_dropout=None):
+        """DistilBERT's train-mode dropout probabilities (default: the HF config's 0.1 / 0.1, as the reference trains)."""
+        self.text_model.set_dropout(dropout, attention_dropout)
+        return self
+
     # ---- reference surface ----------------------------------------------------------------------------------------
     def set_device(self, device):
         self.device = device

@@ -296,14 +296,20 @@ def space_attention_bwd(qkv, addmask, dout, B, F, R):
     return dqkv
 
 
-def full_attention_fwd(q, k, v, addmask, B, L, ld=768):
-    """``ld``: row stride of q / k / v (2304 when they are the three column blocks of one packed projection)."""
+def full_attention_fwd(q, k, v, addmask, B, L, ld=768, keep=None):
+    """``ld``: row stride of q / k / v (2304 when they are the three column blocks of one packed projection).
+    ``keep``: (keep bytes [B*H, Ns, Ns], transposed keep bytes, 1 / (1 - p)) from :func:`attn_keep_masks` -- dropout of the
+    attention probabilities."""
     out = torch.empty((B * L, 768), device=q.device, dtype=q.dtype)
+    if keep is not None:
+        call("dvlp_attention_dropout_next", p(keep[0]), p(keep[1]), float(keep[2]))
     call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(out), 768, SCALE, stream())
     return out
 
 
-def full_attention_bwd(q, k, v, addmask, dout, B, L, ld=768, out=None, ld_out=768):
+def full_attention_bwd(q, k, v, addmask, dout, B, L, ld=768, out=None, ld_out=768, keep=None):
+    if keep is not None:
+        call("dvlp_attention_dropout_next", p(keep[0]), p(keep[1]), float(keep[2]))
     if out is None:
         dq, dk, dv = (torch.empty((B * L, 768), device=q.device, dtype=q.dtype) for _ in range(3))
     else:
@@ -311,6 +317,43 @@ def full_attention_bwd(q, k, v, addmask, dout, B, L, ld=768, out=None, ld_out=76
     call("dvlp_attention_bwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
          ld_out, None, SCALE, stream())
     return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# dropout (text tower, train mode)
+# ----------------------------------------------------------------------------------------------------------------
+def dropout_state(device, seed=0):
+    """Device-resident Philox state {seed_lo, seed_hi, offset, -} (int32 storage of uint32 words)."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    words = [seed & 0xFFFFFFFF, seed >> 32, 0, 0]
+    return torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32, device=device)
+
+
+def dropout_advance(state):
+    call("dvlp_dropout_advance", p(state), stream())
+
+
+def dropout_fwd(x, prob, state, site, res=None):
+    """y = x * keep / (1 - p) (+ res).  Returns (y, keep bytes)."""
+    y = torch.empty_like(x)
+    keep = torch.empty(x.numel(), device=x.device, dtype=torch.uint8)
+    call("dvlp_dropout_fwd", dt(x), x.numel(), p(x), p(res), p(y), p(keep), float(prob), p(state), int(site), stream())
+    return y, keep
+
+
+def dropout_bwd(dy, keep, prob):
+    dx = torch.empty_like(dy)
+    call("dvlp_dropout_bwd", dt(dy), dy.numel(), p(dy), p(keep), float(prob), p(dx), stream())
+    return dx
+
+
+def attn_keep_masks(B, L, prob, state, site, device):
+    """Keep bytes of the [L, L] attention-probability maps of every (batch, head), in both orientations + the rescale factor."""
+    Ns = (L + 15) // 16 * 16
+    keep = torch.empty((B * HEADS, Ns, Ns), device=device, dtype=torch.uint8)
+    keepT = torch.empty_like(keep)
+    call("dvlp_dropout_attn_mask", B * HEADS, L, float(prob), p(state), int(site), p(keep), p(keepT), stream())
+    return keep, keepT, 1.0 / (1.0 - prob)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -1,7 +1,10 @@
 """DistilBERT encoder with HuggingFace's parameter names (``text_model.*`` keys of the reference state_dict), computed
 by the gfx950 kernels.  The reference gets this tower from ``AutoModel.from_pretrained`` (model/model.py:29); the
-arithmetic is third-party (transformers 4.10.0) -- see SURVEY.md section 8(c).  Dropout is not applied (the parity
-fixtures use dropout 0; train-mode dropout 0.1 of the reference is a documented difference).
+arithmetic is third-party (transformers 4.10.0) -- see SURVEY.md section 8(c).  In train mode (the reference leaves the
+text model in train mode, model/model.py:29-30) HuggingFace's three dropouts are applied with the config's ``dropout`` /
+``attention_dropout`` (0.1 in distilbert-base-uncased): after the embedding LayerNorm, on the attention probabilities,
+after the feed-forward's second linear.  Masks are Philox4x32-10 streams from a device-resident state (csrc/dropout.hip);
+``set_dropout(0, 0)`` (what the parity fixtures use) or ``eval()`` turns them off.
 """
 from __future__ import annotations
 
@@ -46,12 +49,12 @@ class _Block(nn.Module):
         self.ffn = _FFN(dim, hidden)
         self.output_layer_norm = _Affine(dim)
 
-    def forward(self, x, addmask, want_relu=False):
+    def forward(self, x, addmask, want_relu=False, drop=None):
         a, f = self.attention, self.ffn
         return Fn.BertLayerFn.apply(x, addmask, a.q_lin.weight, a.q_lin.bias, a.k_lin.weight, a.k_lin.bias, a.v_lin.weight,
                                     a.v_lin.bias, a.out_lin.weight, a.out_lin.bias, self.sa_layer_norm.weight,
                                     self.sa_layer_norm.bias, f.lin1.weight, f.lin1.bias, f.lin2.weight, f.lin2.bias,
-                                    self.output_layer_norm.weight, self.output_layer_norm.bias, want_relu)
+                                    self.output_layer_norm.weight, self.output_layer_norm.bias, want_relu, drop)
 
 
 class _Transformer(nn.Module):
@@ -68,6 +71,8 @@ class _Config:
         self.hidden_dim = kw.get("hidden_dim", 3072)
         self.n_layers = kw.get("n_layers", 6)
         self.n_heads = kw.get("n_heads", 12)
+        self.dropout = float(kw.get("dropout", 0.1))                        # HF DistilBertConfig defaults
+        self.attention_dropout = float(kw.get("attention_dropout", 0.1))
 
 
 class DistilBertEncoder(nn.Module):
@@ -80,6 +85,24 @@ class DistilBertEncoder(nn.Module):
         self.embeddings = _Embeddings(c.vocab_size, c.max_position_embeddings, c.dim)
         self.transformer = _Transformer(c.n_layers, c.dim, c.hidden_dim)
         self.compute_dtype = torch.float32
+        self._drop_state = None
+        self.dropout_seed = 0
+
+    def set_dropout(self, dropout, attention_dropout=None):
+        """Override the config's probabilities (0 / 0: what the parity fixtures were generated with)."""
+        self.config.dropout = float(dropout)
+        self.config.attention_dropout = float(dropout if attention_dropout is None else attention_dropout)
+        return self
+
+    def seed_dropout(self, seed):
+        self.dropout_seed, self._drop_state = int(seed), None
+        return self
+
+    def dropout_state(self, device):
+        from . import ops
+        if self._drop_state is None or self._drop_state.device != device:
+            self._drop_state = ops.dropout_state(device, self.dropout_seed)
+        return self._drop_state
 
     @classmethod
     def from_pretrained(cls, path):
@@ -111,10 +134,17 @@ class DistilBertEncoder(nn.Module):
         addmask = torch.zeros((B, L), device=input_ids.device, dtype=torch.float32)
         addmask.masked_fill_(attention_mask == 0, float("-inf"))
         e = self.embeddings
+        c = self.config
+        dropping = self.training and (c.dropout > 0.0 or c.attention_dropout > 0.0)
+        state = None
+        if dropping:
+            from . import ops
+            state = self.dropout_state(input_ids.device)
+            ops.dropout_advance(state)                       # one new Philox offset per forward (on the device: graph-replayable)
         x = Fn.TextEmbedFn.apply(input_ids.contiguous(), e.word_embeddings.weight, e.position_embeddings.weight, e.LayerNorm.weight,
-                                 e.LayerNorm.bias, self.compute_dtype)
+                                 e.LayerNorm.bias, self.compute_dtype, (c.dropout, state, 0) if dropping and c.dropout > 0.0 else None)
         n = len(self.transformer.layer)
         xr = None
         for i, blk in enumerate(self.transformer.layer):
-            x, xr = blk(x, addmask, want_relu and i == n - 1)
+            x, xr = blk(x, addmask, want_relu and i == n - 1, (c.attention_dropout, c.dropout, state, 1 + 2 * i) if dropping else None)
         return (x, xr) if want_relu else x

@@ -126,6 +126,23 @@ int dvlp_text_embed_fwd(int dtype, int64_t B, int64_t L, const int64_t* ids, con
 int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, const void* de, float* dword, void* stream);
 int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream);
 
+/* ---- dropout of the text tower: the reference keeps DistilBERT in train mode (model/model.py:29-30), so HuggingFace's three
+ *      dropouts (embeddings, attention probabilities, feed-forward output; p = 0.1) are part of every training step.  Masks are
+ *      Philox4x32-10 streams keyed by (seed, step offset, site, element); `state` is DEVICE memory uint32[4] =
+ *      {seed_lo, seed_hi, offset, -}; dvlp_dropout_advance bumps the offset (once per forward; replayable inside a hipGraph). ---- */
+int dvlp_dropout_advance(void* state, void* stream);
+/* y = x * keep / (1 - p) (+ res); keep (uint8 [n], 0/1) is stored for the backward.  n % 4 == 0. */
+int dvlp_dropout_fwd(int dtype, int64_t n, const void* x, const void* res, void* y, void* keep, float p, const void* state, int site, void* stream);
+int dvlp_dropout_bwd(int dtype, int64_t n, const void* dy, const void* keep, float p, void* dx, void* stream);
+/* keep bytes of the attention probabilities of BH = batch * heads [N x N] maps in both orientations: keep[bh][q][key] and
+   keepT[bh][key][q], row stride N rounded up to 16 (pads 0) */
+int dvlp_dropout_attn_mask(int64_t BH, int64_t N, float p, const void* state, int site, void* keep, void* keepT, void* stream);
+/* the NEXT dvlp_attention_fwd / dvlp_attention_bwd (mode 1) issued by this host thread multiplies its probabilities by
+   keep * scale (scale = 1 / (1 - p)): HF MultiHeadSelfAttention's `weights = dropout(softmax(scores))` */
+int dvlp_attention_dropout_next(const void* keep, const void* keepT, float scale);
+/* out[4] = Philox4x32-10(ctr_key[0..3], key = ctr_key[4..5]) computed on the device (known-answer test) */
+int dvlp_philox_kat(const void* ctr_key, void* out, void* stream);
+
 /* ---- local loss: xattn_score_fast / func_attention_fast / focal_equal / cosine_similarity (model/loss.py:209-330) ---- */
 /* testing knob: 1 = always take the general-G (long-video) softmax path, even when the fused per-pair kernels fit LDS */
 int dvlp_xattn_force_general(int on);

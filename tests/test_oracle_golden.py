@@ -192,3 +192,17 @@ def test_eval_pipeline_vs_reference():
     for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
         r = fn(g["o2t_sims"])
         assert np.allclose([r[k] for k in keys], g[name], rtol=1e-9, atol=1e-9), name
+
+
+def test_philox_known_answer_vectors():
+    """The oracle's Philox4x32-10 against the published Random123 known-answer vectors (the HIP dropout masks are checked against
+    this function on the device, tests/test_gpu_round2.py)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = orc.philox4x32_10(*ctr, *key)
+        assert tuple(int(x) for x in got.reshape(-1)) == want
+    keep = orc.dropout_keep_flat(1 << 20, 0.1, seed=1234, offset=1, site=3)
+    assert abs(1.0 - keep.mean() - 0.1) < 2e-3                        # drop rate
+    assert not np.array_equal(keep, orc.dropout_keep_flat(1 << 20, 0.1, seed=1234, offset=2, site=3))
