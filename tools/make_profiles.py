@@ -64,4 +64,39 @@ if fc and wc:
            "gemm_family_traffic_bytes_per_launch": traffic}
     json.dump(out, open(os.path.join(P, tag + "_gemm_hbm_traffic_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+# MFMA-busy, LDS bank conflicts and parked-wave share per kernel family (third PMC pass)
+mc = one("mfma/**/*counter_collection.csv")
+if mc:
+    fam = lambda n: ("gemm_256x256 (p8)" if "p8_kernel" in n else "gemm_wgrad_group (p8g)" if "p8_group_kernel" in n else
+                     "gemm_128x128 (glds)" if "glds_kernel" in n else "attention_mfma" if "mattn" in n else
+                     "local_loss_softmax" if "xsoftmax" in n else "layernorm" if "ln_" in n else None)
+    agg, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    for r in csv.DictReader(open(mc)):
+        f = fam(r["Kernel_Name"])
+        if f:
+            agg[f][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cnt[f] += 1
+    out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES "
+                     "SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 (tools/profile_round.sh)",
+           "note": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs): the gfx94x MfmaUtil formula with GRBM_GUI_ACTIVE, which "
+                   "rocprofv3 reports summed over the 8 XCDs, brought back to one clock (cross-check: p8 kernels 0.30 busy ~ 750 TFLOP/s of 2500; ROCm 7.2 ships no gfx950 "
+                   "derived-counter section); lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
+                   "(share of wave time at s_waitcnt / barriers); mfma_ops_bf16 are 512-FLOP units per MI355X_MICROARCH.md",
+           "families": {}}
+    for f, c in agg.items():
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        out["families"][f] = {"launches": cnt[f],
+                              "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(gui / 8.0 * 256 * 4, 1.0), 4),
+                              "lds_conflict": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4),
+                              "parked": round(c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0), 4),
+                              "gpu_cycles_per_launch": round(gui / 8.0 / max(cnt[f], 1)),
+                              "mfma_mops_bf16_per_launch": round(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / max(cnt[f], 1))}
+    json.dump(out, open(os.path.join(P, tag + "_mfma_lds_pmc.json"), "w"), indent=1)
+    print(json.dumps(out["families"], indent=1))
+for extra in ("select_bench.txt", "xfused_check.txt"):
+    src = os.path.join(SRC, extra)
+    if os.path.exists(src):
+        keep = [l for l in open(src) if "amdgpu.ids" not in l]
+        open(os.path.join(P, tag + "_" + extra), "w").writelines(keep)
 print(line[:400])

@@ -11,6 +11,11 @@ timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/write.err
+# MFMA-busy / LDS-bank-conflict / wait counters of the same command (third PMC pass; SQ + GRBM slots only)
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline --no-object-tower > /dev/null 2> $O/mfma.err
+# K1 alone and the local-loss kernels alone
+timeout 300 python3 $R/tools/select_bench.py > $O/select_bench.txt 2>&1
+timeout 300 python3 $R/tools/xfused_check.py > $O/xfused_check.txt 2>&1
 # keep what travels back small: the per-dispatch traces are large
-for d in trace fetch write; do find $O/$d -name "*kernel_trace.csv" -size +20M -delete; done
-ls -la $O $O/trace $O/fetch $O/write
+for d in trace fetch write mfma; do find $O/$d -name "*kernel_trace.csv" -size +20M -delete; done
+ls -la $O $O/trace $O/fetch $O/write $O/mfma
