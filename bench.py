@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--p8", type=int, default=-1, help="override dvlp_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
     ap.add_argument("--no-object-tower", action="store_true", help="skip the object-transformer-only fwd+bwd timing")
-    ap.add_argument("--parallel-towers", type=int, default=0, help="1: text tower on its own HIP stream, concurrent with the object tower")
+    ap.add_argument("--parallel-towers", type=int, default=1, help="1 (default): text tower on its own HIP stream, concurrent with the object tower; 0: one stream")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
                          "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
@@ -239,6 +239,7 @@ def main():
     sync()
     timing_inline = not a.no_kernel_timing and not use_graph
     if timing_inline:
+        model.parallel_towers = False                    # per-launch event timings need one stream
         ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -252,6 +253,7 @@ def main():
     if not a.no_kernel_timing and use_graph:
         # per-launch HIP events cannot be recorded inside a captured graph: the GEMM family is timed over an equally long EAGER
         # region right behind the replayed one (same kernels, same shapes, same launch order, the stream they are launched on)
+        model.parallel_towers = False                # one stream: per-launch event timings are only meaningful without concurrent kernels
         stepper._eager(data)
         sync()
         ops.prof_enable(True)
@@ -302,7 +304,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "optimizer": "fused HF-AdamW",
                        "negatives": "all-gathered" if gather is not None else "per-rank (reference default)",
                        "step1_loss": None if step1_loss is None else round(step1_loss, 4), "final_loss": round(final_loss, 4)},
-            "launch_mode": "hipGraph replay (1 graph per step)" if use_graph else "eager",
+            "launch_mode": ("hipGraph replay (1 graph per step)" if use_graph else "eager") + (", text tower on its own stream" if a.parallel_towers else ""),
             "host_enqueue_ms_per_step": round(1e3 * host_elapsed / a.steps, 3),
             "step_model_tflops": round(value * fpp / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * fpp / 1e12 / (peak * world), 4),

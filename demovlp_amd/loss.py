@@ -67,6 +67,17 @@ class RWALoss(nn.Module):
         return Fn.RWATailFn.apply(scores, float(self.lambda_softmax))
 
 
+class CrossEntropy(nn.Module):
+    """model/loss.py:180-187: the QA fine-tuning loss (configs/ft/*_qa-select.json), on the [B, num_label] logits of ObjectQARelation."""
+
+    def __init__(self):
+        super().__init__()
+        self.loss = nn.CrossEntropyLoss()
+
+    def forward(self, output, target):
+        return self.loss(output, target)
+
+
 class GlobalLocalLoss(nn.Module):
     def __init__(self, temperature=0.05, lambda_softmax=20, focal_type="prob", margin=0, max_violation=False, use_local=True,
                  use_global=True, coef=1000.0):

@@ -164,6 +164,45 @@ class ObjectRelation(nn.Module):
         self.load_state_dict(toload, strict=False)
 
 
+class ObjectQARelation(ObjectRelation):
+    """Video question answering: the two towers + `BUTDQAHead` (mirror of model/model.py:200-289).  ``object_params`` carries
+    ``num_label`` (configs/ft/msrvtt_qa-select.json:15).  ``forward(data) -> {'logits': [B, num_label]}``; the text embedding is
+    the max over ALL 100 token projections (:285, padded tokens included, as the reference), the object side the local region
+    embeddings with the loader's 0/1 region mask."""
+
+    def __init__(self, object_params, text_params, projection_dim=256, load_checkpoint=None, projection="minimal",
+                 load_temporal_fix="bilinear", compute_dtype="float32"):
+        super().__init__(object_params, text_params, projection_dim, None, projection, load_temporal_fix, compute_dtype)
+        from .video_qa_model import BUTDQAHead
+        self.head = BUTDQAHead(v_dim=256, q_dim=256, hid_dim=256, out_dim=object_params["num_label"])
+        if load_checkpoint not in ["", None]:
+            checkpoint = torch.load(load_checkpoint, map_location="cpu")
+            new_state_dict = self._inflate_positional_embeds(state_dict_data_parallel_fix(checkpoint["state_dict"], self.state_dict()))
+            try:
+                self.load_state_dict(new_state_dict, strict=True)
+            except Exception as e:
+                print("Parameters of model and state_dict are mismatched. {}".format(e))
+                self.load_state_dict_with_mismatch(new_state_dict)
+
+    def forward(self, data, return_embeds=True):
+        text_data = data["text"]
+        ids = text_data["input_ids"]
+        if not ids.is_cuda:
+            raise DemoVLPHipError("ObjectQARelation runs on an MI355X device only (no CPU fallback): move the batch to cuda")
+        h, hr = self.text_model(input_ids=ids, attention_mask=text_data.get("attention_mask"), want_relu=True)
+        lin = self.txt_proj[1]
+        text_embeddings = Fn.LinearFn.apply(hr, lin.weight, lin.bias, h)              # [B, 100, 256]
+        object_embeddings, _ = self.object_model(data["object"], data["object_mask"])
+        return dict(logits=self.compute_fusion(text_embeddings, object_embeddings, text_data.get("attention_mask"), data["object_mask"]))
+
+    def compute_fusion(self, text_embeddings, object_embeddings, text_mask, object_mask):
+        if object_mask.dim() == 3:
+            object_mask = object_mask.reshape(object_mask.shape[0], -1)
+        object_mask = object_mask.to(torch.float32)
+        text_embeddings, _ = torch.max(text_embeddings.float(), dim=1)
+        return self.head(text_embeddings, object_embeddings[:, 1:].float(), object_mask)
+
+
 def sim_matrix(a, b, eps=1e-8):
     """model/model.py:582-590 for any [N,256] x [M,256].  Rows are l2-normalised with max(|.|, 1e-8), then a_n b_n^T.  Host
     tensors (the reference's validation path hands over .cpu() tensors, trainer_dist.py:369) are staged through the GPU and the

@@ -98,6 +98,23 @@ def caption_batch(batch: int, first_sample: int = 0, text_len: int = TEXT_LEN):
 # --------------------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------------------
+def qa_head_schema(num_label: int) -> "dict[str, tuple]":
+    """`head.*` tensors of ObjectQARelation (BUTDQAHead, model/video_qa_mdoel.py:78-97; weight-normalised linears carry weight_g / weight_v)."""
+    s: "dict[str, tuple]" = {}
+    for p in ("head.v_att.v_proj.main.0", "head.v_att.q_proj.main.0", "head.classifier.q_net.main.0", "head.classifier.v_net.main.0"):
+        s[p + ".bias"] = (256,)
+        s[p + ".weight_g"] = ()
+        s[p + ".weight_v"] = (256, 256)
+    s["head.v_att.linear.bias"] = (1,)
+    s["head.v_att.linear.weight_g"] = ()
+    s["head.v_att.linear.weight_v"] = (1, 256)
+    s["head.classifier.main.0.weight"] = (512, 256)
+    s["head.classifier.main.0.bias"] = (512,)
+    s["head.classifier.main.3.weight"] = (num_label, 512)
+    s["head.classifier.main.3.bias"] = (num_label,)
+    return s
+
+
 def state_dict_schema(num_frames: int, object_num: int, time_module=None) -> "dict[str, tuple]":
     """Name -> shape of every tensor in ``ObjectRelation.state_dict()`` (280 tensors, + 4 per block
     with ``time_module='timeattn'``: model/object_transformer.py:227-234)."""
@@ -168,6 +185,8 @@ def fill_tensor(name: str, shape) -> np.ndarray:
     is_norm = ("norm" in name.lower()) and len(shape) == 1
     if is_norm and leaf == "weight":
         return (1.0 + 0.1 * z).astype(np.float32)
+    if leaf == "weight_g":
+        return np.asarray(4.0 + 0.5 * z, dtype=np.float32)  # weight-norm gain (a scalar: dim=None)
     if leaf == "bias":
         return (0.02 * z).astype(np.float32)
     if name in ("object_model.proj.weight", "txt_proj.1.weight"):
@@ -177,5 +196,8 @@ def fill_tensor(name: str, shape) -> np.ndarray:
     return (0.02 * z).astype(np.float32)
 
 
-def fill_state_dict(num_frames: int, object_num: int, time_module=None) -> "dict[str, np.ndarray]":
-    return {k: fill_tensor(k, shp) for k, shp in state_dict_schema(num_frames, object_num, time_module).items()}
+def fill_state_dict(num_frames: int, object_num: int, time_module=None, qa_labels: int = 0) -> "dict[str, np.ndarray]":
+    schema = state_dict_schema(num_frames, object_num, time_module)
+    if qa_labels:
+        schema.update(qa_head_schema(qa_labels))
+    return {k: fill_tensor(k, shp) for k, shp in schema.items()}

@@ -243,6 +243,29 @@ def model_forward(p, input_ids, att_mask01, obj, mask01, drop=None):
 
 
 # ==================================================================================================
+# (f4)  QA head: ObjectQARelation.forward + BUTDQAHead (model/model.py:260-289, model/video_qa_mdoel.py:58-97)
+# ==================================================================================================
+def _wn_linear(p, pre, x):
+    """weight_norm(nn.Linear, dim=None): w = g * v / |v|_F (one scalar gain for the whole matrix)."""
+    v = p[pre + ".weight_v"]
+    return x @ (p[pre + ".weight_g"] * v / v.norm()).t() + p[pre + ".bias"]
+
+
+def qa_logits(p, input_ids, att_mask01, obj, mask01):
+    t = text_encoder(p, input_ids, att_mask01)                         # [B, 100, 256]
+    o, _ = object_encoder(p, obj, mask01)
+    q = t.max(dim=1).values                                            # max over all tokens, padded ones included (model.py:285)
+    v = o[:, 1:]
+    m = mask01.reshape(mask01.shape[0], -1).to(v.dtype)
+    fc = lambda pre, x: torch.relu(_wn_linear(p, pre + ".main.0", x))
+    logits = _wn_linear(p, "head.v_att.linear", fc("head.v_att.v_proj", v) * fc("head.v_att.q_proj", q)[:, None]) * m[..., None]
+    att = torch.softmax(logits, dim=1)                                 # padded regions keep logit 0 (mask is multiplied, not added)
+    joint = fc("head.classifier.q_net", q) * fc("head.classifier.v_net", (att * v).sum(1))
+    h = torch.relu(joint @ p["head.classifier.main.0.weight"].t() + p["head.classifier.main.0.bias"])
+    return h @ p["head.classifier.main.3.weight"].t() + p["head.classifier.main.3.bias"]
+
+
+# ==================================================================================================
 # A9-A11  losses
 # ==================================================================================================
 def sim_matrix(a, b, eps=1e-8):

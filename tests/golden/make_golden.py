@@ -365,6 +365,40 @@ def golden_loss_curve(ref_model, ref_loss, ref_data, scratch):
     np.savez_compressed(os.path.join(HERE, "g8_loss_curve.npz"), **out)
 
 
+def golden_qa(ref_model, ref_loss, ref_data, scratch):
+    """G10: ObjectQARelation (model/model.py:200-289) + BUTDQAHead in eval mode (the head's Attention has dropout 0.2) + the
+    CrossEntropy loss (model/loss.py:180-187) on a synthetic MSRVTT-QA-shape batch: F=8, R=30, B=4, 50 answer classes."""
+    F, R, B, NL = 8, 30, 4, 50
+    m = ref_model.ObjectQARelation(
+        object_params={"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": "", "num_label": NL},
+        text_params={"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True})
+    sd = m.state_dict()
+    want = syn.fill_state_dict(F, R, None, NL)
+    assert set(sd.keys()) == set(want.keys()), set(sd.keys()) ^ set(want.keys())
+    with torch.no_grad():
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(want[k].shape), (k, v.shape, want[k].shape)
+            v.copy_(torch.from_numpy(np.asarray(want[k])))
+    m.eval()
+    data = _reference_batch(ref_data, scratch, F, R, B)
+    label = torch.tensor([3, 17, 0, 42])
+    logits = m(data)["logits"]
+    loss = ref_loss.CrossEntropy()(logits, label)
+    loss.backward()
+    out = dict(F=F, R=R, B=B, num_label=NL, label=label.numpy(), logits=logits.detach().numpy(), loss=np.array([loss.item()]))
+    names, norms = [], []
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            names.append(k)
+            norms.append(float(prm.grad.double().norm()))
+            if k.startswith("head.") and prm.grad.numel() <= 4096:
+                out["grad/" + k] = prm.grad.numpy()
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, np.float64)
+    np.savez_compressed(os.path.join(HERE, "g10_qa.npz"), **out)
+    print("g10 loss", loss.item(), "logits range", float(logits.min()), float(logits.max()))
+
+
 def golden_eval(ref_model, ref_loss, ref_data, scratch):
     """G9: the reference's retrieval evaluation (trainer/trainer_dist.py:205-408 with n_gpu = 1) on a synthetic MSRVTT-shape set:
     configs/ft/msrvtt_o2t-select.json geometry (F=8, R=30), 96 video-caption pairs in batches of 32.  Per-batch validation loss,
@@ -419,6 +453,8 @@ def main():
             golden_loss_curve(ref_model, ref_loss, ref_data, scratch)
         if "g9" in only:
             golden_eval(ref_model, ref_loss, ref_data, scratch)
+        if "g10" in only:
+            golden_qa(ref_model, ref_loss, ref_data, scratch)
         return
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
@@ -430,6 +466,7 @@ def main():
     golden_model(ref_model, ref_loss, ref_data, scratch, F=4, R=12, B=2, tag="F4_R12_B2_timeattn", time_module="timeattn")
     golden_loss_curve(ref_model, ref_loss, ref_data, scratch)
     golden_eval(ref_model, ref_loss, ref_data, scratch)
+    golden_qa(ref_model, ref_loss, ref_data, scratch)
 
 
 if __name__ == "__main__":

@@ -596,3 +596,54 @@ def test_graph_replay_draws_fresh_dropout_masks():
         runs.append([float((stepper(data) if graphed else train_step(model, lf, opt, data))[0].item()) for _ in range(6)])
     assert len(set(runs[1])) == 6, runs[1]
     assert runs[0] == runs[1], runs
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_parallel_towers_give_identical_results(graphed):
+    """ObjectRelation.parallel_towers: the text tower on its own HIP stream, concurrent with the object tower (forward and, through
+    autograd's stream bookkeeping, backward).  Same kernels, same order per tower: losses and parameters over 4 steps are bit-equal
+    to the single-stream run, eagerly and inside the captured graph."""
+    F, R, B = 8, 36, 4
+    obj, mask = syn.fast_region_batch(B, F, R, seed=5)
+    ids, att = syn.caption_batch(B)
+    data = to_dev(obj, mask, ids, att)
+    res = []
+    for par in (False, True):
+        from demovlp_amd import functional as Fn
+        Fn.SHADOWS.clear()
+        model = build(F, R, "bfloat16")
+        model.parallel_towers = par
+        arena = ParamArena(model, bf16_shadow=True)
+        opt = FusedAdamW(arena, lr=1e-4)
+        lf = loss_head()
+        stepper = GraphedTrainStep(model, lf, opt, warmup=2) if graphed else None
+        losses = [float((stepper(data) if graphed else train_step(model, lf, opt, data))[0].item()) for _ in range(5)]
+        torch.cuda.synchronize()
+        res.append((losses, arena.flat_p[::1013].clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+
+
+def test_qa_model_vs_reference_golden():
+    """SURVEY 8(f) rank 4, second half: ObjectQARelation (towers on the HIP path + BUTDQAHead) and CrossEntropy against golden G10
+    produced by the imported reference: state_dict keys, logits, loss, gradient norms (fp32, eval mode as in the fixture)."""
+    from demovlp_amd.loss import CrossEntropy
+    from demovlp_amd.model import ObjectQARelation
+    g = load_golden("g10_qa.npz")
+    F, R, B, NL = int(g["F"]), int(g["R"]), int(g["B"]), int(g["num_label"])
+    m = ObjectQARelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None, "num_label": NL},
+                         {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True})
+    sd = syn.fill_state_dict(F, R, None, NL)
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.to(DEV).eval()
+    data = to_dev(*golden_batch(F, R, B))
+    logits = m(data)["logits"]
+    assert logits.shape == (B, NL) and rel_err(logits.detach().cpu().numpy(), g["logits"]) < 1e-4
+    loss = CrossEntropy()(logits, torch.from_numpy(g["label"]).to(DEV))
+    assert abs(loss.item() - g["loss"][0]) < 1e-4
+    loss.backward()
+    named = dict(m.named_parameters())
+    bad = [(k, float(named[k].grad.double().norm()), n) for k, n in zip(g["grad_names"], g["grad_norms"])
+           if abs(float(named[k].grad.double().norm()) - n) > 2e-3 * max(n, 1e-6)]
+    assert not bad, bad[:5]

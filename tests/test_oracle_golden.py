@@ -206,3 +206,20 @@ def test_philox_known_answer_vectors():
     keep = orc.dropout_keep_flat(1 << 20, 0.1, seed=1234, offset=1, site=3)
     assert abs(1.0 - keep.mean() - 0.1) < 2e-3                        # drop rate
     assert not np.array_equal(keep, orc.dropout_keep_flat(1 << 20, 0.1, seed=1234, offset=2, site=3))
+
+
+def test_qa_head_vs_reference():
+    """G10: ObjectQARelation + BUTDQAHead + CrossEntropy of the imported reference (eval mode) against the oracle: logits, loss, and
+    the gradient norms of every tensor that receives one."""
+    g = load_golden("g10_qa.npz")
+    F, R, B, NL = int(g["F"]), int(g["R"]), int(g["B"]), int(g["num_label"])
+    obj, mask, ids, att = golden_batch(F, R, B)
+    torch.set_num_threads(8)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R, None, NL), requires_grad=True)
+    logits = orc.qa_logits(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask).float())
+    assert rel_err(logits.detach().numpy(), g["logits"]) < 1e-5
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["label"]))
+    assert abs(loss.item() - g["loss"][0]) < 1e-5
+    loss.backward()
+    for k, n in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(float(p[k].grad.double().norm()) - n) <= 1e-3 * max(n, 1e-6), k
