@@ -81,6 +81,8 @@ class _Staging:
         self.feat, self.box = mk(batch, frames, max_regions, FEAT_DIM), mk(batch, frames, max_regions, 4)
         self.conf, self.wh = mk(batch, frames, max_regions), mk(batch, frames, 2)
         self.n = mk(batch, frames, dt=torch.int32)
+        # numpy views of the same (pinned) memory: plain memcpys that release the GIL, so frames can be staged from several threads
+        self.nfeat, self.nbox, self.nconf, self.nwh, self.nn = (t.numpy() for t in (self.feat, self.box, self.conf, self.wh, self.n))
         self.copied = torch.cuda.Event() if pin else None
         self.in_flight = False
 
@@ -110,6 +112,7 @@ class RegionBatcher:
         self.cur = 0
         self.copy_stream = torch.cuda.Stream(device=self.device) if pin else None
         self.bytes_staged = 0
+        self._pool, self._pool_n = None, 0
 
     # the staging set being filled (kept as attributes for callers that peek at the buffers)
     @property
@@ -126,12 +129,21 @@ class RegionBatcher:
             raise ValueError(f"frame has {n} regions, staging buffers hold {self.M}")
         s = self.bufs[self.cur]
         s.wait_reusable()
-        s.feat[b, f, :n] = torch.from_numpy(x)
-        s.box[b, f, :n] = torch.from_numpy(bbox)
-        s.conf[b, f, :n] = torch.from_numpy(conf)
-        s.conf[b, f, n:] = -1.0                                   # never selected: real confidences are positive
-        s.wh[b, f, 0], s.wh[b, f, 1] = wh
-        s.n[b, f] = n
+        s.nfeat[b, f, :n] = x
+        s.nbox[b, f, :n] = bbox
+        s.nconf[b, f, :n] = conf
+        s.nconf[b, f, n:] = -1.0                                  # never selected: real confidences are positive
+        s.nwh[b, f, 0], s.nwh[b, f, 1] = wh
+        s.nn[b, f] = n
+
+    def stage_frames(self, items, workers: int = 8) -> None:
+        """Stage many frames ``(b, f, x, bbox, conf, wh)`` from a thread pool (the memcpys into pinned memory release the GIL): the
+        host-side counterpart of the reference's DataLoader worker processes (base/base_data_loader.py:23-38)."""
+        from concurrent.futures import ThreadPoolExecutor
+        self.bufs[self.cur].wait_reusable()
+        if self._pool is None or self._pool_n != workers:
+            self._pool, self._pool_n = ThreadPoolExecutor(max_workers=workers), workers
+        list(self._pool.map(lambda it: self.stage(*it), items, chunksize=max(1, len(items) // (4 * workers)) if hasattr(items, "__len__") else 1))
 
     def stage_video(self, b: int, frame_dir: str, frame_idxs: Sequence[int]) -> None:
         for f, idx in enumerate(frame_idxs):
