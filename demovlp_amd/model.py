@@ -203,6 +203,15 @@ class ObjectQARelation(ObjectRelation):
         return self.head(text_embeddings, object_embeddings[:, 1:].float(), object_mask)
 
 
+class ObjectMCRelation(ObjectRelation):
+    """Multiple-choice evaluation model (model/model.py:393-579): the same two towers, `forward` and state_dict as ObjectRelation
+    (the reference class is a copy of it; only the trainer that consumes the embeddings differs)."""
+
+    def __init__(self, object_params, text_params, projection_dim=256, load_checkpoint=None, projection="minimal",
+                 load_temporal_fix="zeros", compute_dtype="float32"):
+        super().__init__(object_params, text_params, projection_dim, load_checkpoint, projection, load_temporal_fix, compute_dtype)
+
+
 def sim_matrix(a, b, eps=1e-8):
     """model/model.py:582-590 for any [N,256] x [M,256].  Rows are l2-normalised with max(|.|, 1e-8), then a_n b_n^T.  Host
     tensors (the reference's validation path hands over .cpu() tensors, trainer_dist.py:369) are staged through the GPU and the
