@@ -1199,6 +1199,8 @@ static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: meas
 extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
 extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
+static int g_wgrad_split = 0;    // grouped weight gradients: 0 = automatic uniform K split, > 0 = forced
+extern "C" int dvlp_wgrad_group_split(int s) { g_wgrad_split = s; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
 extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
 extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
@@ -1444,14 +1446,12 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
         if (S[p] > K[p] / 256) S[p] = K[p] / 256;
         total += tiles[p] * S[p];
     }
-    // spend the remaining CUs on the problems whose blocks run longest
-    for (;;) {
-        int best = -1;
-        for (int p = 0; p < count; ++p)
-            if (total + tiles[p] <= 256 && S[p] < K[p] / 256 && (best < 0 || K[p] / S[p] > K[best] / S[best])) best = p;
-        if (best < 0) break;
-        S[best] += 1; total += tiles[best];
-    }
+    // The same K split for every problem of the group (they share K = batch x tokens): measured on MI355X, giving the CUs left over
+    // by the uniform split to one problem as a third K slice (108 tiles: S = 3,2,2,2 -> 252 blocks instead of 216) made the whole
+    // launch SLOWER -- 403 us against 309 us for a ViT layer's four products, 166 against 122 for a DistilBERT layer's -- although
+    // it shortens a third of the blocks: tools/wgrad_bench.py.  g_wgrad_split > 0 forces a split (A/B measurements).
+    if (g_wgrad_split > 0)
+        for (int p = 0; p < count; ++p) { S[p] = g_wgrad_split; if (S[p] > K[p] / 256) S[p] = K[p] / 256 > 0 ? K[p] / 256 : 1; }
     // slabs for every split problem must fit the split-K workspace; otherwise split less
     for (;;) {
         int64_t need = 0;

@@ -47,6 +47,9 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
    host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
+/* K split of the grouped weight-gradient launch: 0 (default) = automatic (the same split for every problem), > 0 = forced -- for
+   A/B measurements (tools/wgrad_bench.py) */
+int dvlp_wgrad_group_split(int s);
 /* The next dvlp_gemm issued by this host thread also produces dst[N] (fp32) = column sums of its stored output C -- e.g. the bias
    gradient of fc1 out of the GEMM that computes d(pre-activation).  Fused into the 256 x 256 kernel's epilogue when the deferred
    reductions (dvlp_reduce_defer) are on -- final after dvlp_reduce_flush --, otherwise a dvlp_colsum pass right after the GEMM

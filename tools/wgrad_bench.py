@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tokens", type=int, default=18496)
 ap.add_argument("--alias", action="store_true")
 ap.add_argument("--separate", action="store_true", help="four dvlp_gemm launches instead of the grouped one")
+ap.add_argument("--subset", default="", help="comma list of problem indices (0 fc2, 1 fc1, 2 proj, 3 qkv)")
 a = ap.parse_args()
 dev = "cuda"
 T = a.tokens
@@ -31,6 +32,10 @@ def mat(rows, cols):
 
 shapes = [("fc2", 768, 3072), ("fc1", 3072, 768), ("proj", 768, 768), ("qkv", 2304, 768)]       # dW [N_out, K_in] = dy[T, N_out]^T x[T, K_in]
 probs = [(mat(T, n), mat(T, k), torch.empty(n, k, device=dev, dtype=torch.float32)) for _, n, k in shapes]
+if a.subset:
+    keep = [int(x) for x in a.subset.split(',')]
+    shapes = [shapes[i] for i in keep]
+    probs = [probs[i] for i in keep]
 flops = sum(2.0 * T * n * k for _, n, k in shapes)
 
 
@@ -53,7 +58,7 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 us = 1e3 * e0.elapsed_time(e1) / n
-print(f"wgrad group T={T} alias={a.alias} separate={a.separate}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s")
-if not a.alias:
+print(f"wgrad group T={T} alias={a.alias} separate={a.separate} subset={a.subset}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s")
+if not a.alias and not a.subset:
     ref = probs[2][0].float().t() @ probs[2][1].float()
     print("   proj dW rel err vs torch fp32:", float((probs[2][2] - ref).abs().max() / ref.abs().max()))
