@@ -1199,6 +1199,8 @@ static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: meas
 extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
 extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
+static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
+extern "C" int dvlp_gemm_force_split(int s) { g_force_split = s; return DVLP_OK; }
 static int g_wgrad_split = 0;    // grouped weight gradients: 0 = automatic uniform K split, > 0 = forced
 extern "C" int dvlp_wgrad_group_split(int s) { g_wgrad_split = s; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
@@ -1334,7 +1336,10 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         // ... and a tile count that fills whole rounds of the 256 CUs (300 tiles = 2 rounds for 1.17 rounds of work); a long K
         // (>= 32 K tiles) amortises its fixed costs well enough to win even at 75 tiles
         const bool rounds8 = 10 * tiles8 >= 8 * 256 * cdiv(tiles8, 256);
-        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 <= 64 && K >= 4096) || (tiles8 >= 64 && tiles8 < 192 && K >= 2048))));
+        // (measured per shape with tools/gemm_sweep.py: 75-tile outputs with K = 2304 / 3072 -- the text tower's fc2, fc1 dX, qkv dX -- run
+        //  faster on the 128-row kernel without a K split than on a 3-way split 256-row launch (47 vs 55, 38 vs 50, 48 vs 55 us), and a
+        //  3-tile weight gradient -- the two 256-wide projections -- on 384 128-row blocks than on 96 256-row ones)
+        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 >= 8 && tiles8 <= 64 && K >= 4096))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
         // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32
         // slabs (deterministic, no float atomics).
@@ -1343,12 +1348,13 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         const WsEntry wse = ws_for(stream);
         float* g_ws = wse.ptr;
         const int64_t g_ws_bytes = wse.bytes;
-        if (g_ws && tiles < (p8 ? 128 : 384) && K >= 1024) {
+        if (g_ws && tiles < (p8 ? 128 : 200) && K >= 1024) {
             S = p8 ? 256 / tiles : (g_splitk_target + tiles - 1) / tiles;
             if (S > K / 256) S = K / 256;
             if (S > 32) S = 32;
             while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;
         }
+        if (g_force_split > 0 && g_ws) { S = g_force_split; while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S; }
         int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;
         S = cdiv(K, kchunk);
         float* slab = S > 1 ? g_ws : nullptr;

@@ -47,6 +47,8 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
    host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
+/* K split of dvlp_gemm's bf16 kernels: 0 (default) = automatic, > 0 = forced -- for A/B measurements (tools/gemm_sweep.py) */
+int dvlp_gemm_force_split(int s);
 /* K split of the grouped weight-gradient launch: 0 (default) = automatic (the same split for every problem), > 0 = forced -- for
    A/B measurements (tools/wgrad_bench.py) */
 int dvlp_wgrad_group_split(int s);
