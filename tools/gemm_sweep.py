@@ -38,7 +38,10 @@ CASES = [("text qkv fwd", "fwd", 6400, 2304, 768), ("text out fwd", "fwd", 6400,
          ("text fc1 dX", "dx", 6400, 3072, 768), ("text fc2 dX", "dx", 6400, 768, 3072),
          ("obj proj256 fwd", "fwd", 18496, 256, 768), ("obj proj256 dX", "dx", 18496, 256, 768), ("obj proj256 dW", "dw", 18496, 256, 768),
          ("txt proj256 fwd", "fwd", 6400, 256, 768), ("txt proj256 dX", "dx", 6400, 256, 768), ("txt proj256 dW", "dw", 6400, 256, 768),
-         ("embed fwd", "fwd", 18432, 768, 2048), ("embed dW", "dw", 18432, 768, 2048)]
+         ("embed fwd", "fwd", 18432, 768, 2048), ("embed dW", "dw", 18432, 768, 2048),
+         ("obj qkv fwd", "fwd", 18496, 2304, 768), ("obj out fwd", "fwd", 18496, 768, 768), ("obj fc1 fwd", "fwd", 18496, 3072, 768),
+         ("obj fc2 fwd", "fwd", 18496, 768, 3072), ("obj qkv dX", "dx", 18496, 2304, 768), ("obj out dX", "dx", 18496, 768, 768),
+         ("obj fc1 dX", "dx", 18496, 3072, 768), ("obj fc2 dX", "dx", 18496, 768, 3072)]
 only = sys.argv[1:] 
 for label, kind, T, N, K in CASES:
     if only and not any(o in label for o in only):
