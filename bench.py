@@ -178,11 +178,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}")
     import torch
     import torch.distributed as dist
+    # developer / test switch: DVLP_BENCH_ONE_GPU=1 puts every rank on cuda:0 with gloo collectives, so the self-launch and the whole
+    # N > 1 code path (graph + post-graph all-reduce, per-rank gathers, max-over-ranks timing) can be exercised on a one-GPU box
+    one_gpu = os.environ.get("DVLP_BENCH_ONE_GPU") is not None
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = world == 1 and os.environ.get("DVLP_FORCE_DIST") is not None and "MASTER_ADDR" in os.environ   # developer switch:
     if world > 1 or force_dist:                                                                              # RCCL path on one GPU
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from demovlp_amd import ops, synthetic as syn
     from demovlp_amd.loss import GlobalLocalLoss

@@ -647,3 +647,19 @@ def test_qa_model_vs_reference_golden():
     bad = [(k, float(named[k].grad.double().norm()), n) for k, n in zip(g["grad_names"], g["grad_norms"])
            if abs(float(named[k].grad.double().norm()) - n) > 2e-3 * max(n, 1e-6)]
     assert not bad, bad[:5]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the driver's scaling command): the parent starts two fresh ranks
+    through torch.distributed.run on 127.0.0.1 and relays rank 0's JSON line.  On this one-GPU box the ranks share cuda:0 and use gloo
+    (DVLP_BENCH_ONE_GPU; RCCL needs one device per rank) -- everything else is the N > 1 path: the captured step per rank, the
+    gradient all-reduce behind the graph, per-rank rates, max-over-ranks timing, whole-job pairs/s."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DVLP_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline", "--no-object-tower"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert len(out["per_rank_pairs_per_s"]) == 2 and all(x > 0 for x in out["per_rank_pairs_per_s"])
+    assert out["value"] > 0 and out["grad_allreduce_ms_standalone"] > 0 and np.isfinite(out["config"]["final_loss"])
