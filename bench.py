@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
     ap.add_argument("--no-object-tower", action="store_true", help="skip the object-transformer-only fwd+bwd timing")
     ap.add_argument("--parallel-towers", type=int, default=1, help="1 (default): text tower on its own HIP stream, concurrent with the object tower; 0: one stream")
+    ap.add_argument("--text-dropout", type=float, default=-1.0,
+                    help="DistilBERT dropout / attention_dropout probability; default: the HF config's 0.1, active in train mode as in the "
+                         "reference (model/model.py:29-30); 0 switches it off")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
                          "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
@@ -203,6 +206,8 @@ def main():
                            {"model": "", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=cdt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R).items()})
     model.to(dev)
+    if a.text_dropout >= 0.0:
+        model.set_text_dropout(a.text_dropout)
     import demovlp_amd.functional as Fn
     Fn.OVERLAP_WGRAD = int(a.overlap_wgrad)
     if a.p8 >= 0:
@@ -311,6 +316,7 @@ def main():
                                    "region features + random 100-token captions, per-GPU batch %d" % (F, R, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "optimizer": "fused HF-AdamW",
                        "negatives": "all-gathered" if gather is not None else "per-rank (reference default)",
+                       "text_dropout": model.text_model.config.dropout,
                        "step1_loss": None if step1_loss is None else round(step1_loss, 4), "final_loss": round(final_loss, 4)},
             "launch_mode": ("hipGraph replay (1 graph per step)" if use_graph else "eager") + (", text tower on its own stream" if a.parallel_towers else ""),
             "host_enqueue_ms_per_step": round(1e3 * host_elapsed / a.steps, 3),

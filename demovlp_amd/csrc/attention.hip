@@ -571,10 +571,9 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
             const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                float m4[4];
-                keep4(kr + 16 * kt + 4 * g, a.kscale, m4);
+                const uint32_t kw = *(const uint32_t*)(kr + 16 * kt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[kt][qt][r] *= m4[r];
+                for (int r = 0; r < 4; ++r) st[kt][qt][r] *= ((kw >> (8 * r)) & 1u) ? a.kscale : 0.f;
             }
         }
     }
@@ -1017,7 +1016,7 @@ __global__ __launch_bounds__(64) void attn_bwd_cls_post_kernel(AttnArgs a) {
 // backward, full (text) mode: one workgroup per (b, h); K, Q and dO tiles are staged once in LDS and shared; wave w owns
 // query tiles {2w, 2w+1} for dQ (layout 1) and key tiles {2w, 2w+1} for dK / dV (layout 2).  NT = ceil(L / 16) <= 8.
 template <int NT>
-__global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mattn_bwd_full_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     constexpr int NTP = (NT + 1) & ~1, ROWS = 16 * NTP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
@@ -1060,6 +1059,19 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
         if (qt >= NT) break;
         const bf16x8 q0 = rowfrag(Qs, qt, 0), q1 = rowfrag(Qs, qt, 1), g0 = rowfrag(Gs, qt, 0), g1 = rowfrag(Gs, qt, 1);
         f32x4 st[NT], dp[NT];
+        // keep bytes of (query 16 qt + c, keys 16 kt + 4 g .. + 3): fetched ahead of the products that hide the round trip, and held
+        // as packed words (float multipliers here cost a wave of occupancy)
+        uint32_t kw[NT];
+        if (a.keep) {
+            int qi = 16 * qt + c;
+            qi = qi < a.N ? qi : a.N - 1;
+            const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) kw[kt] = *(const uint32_t*)(kr + 16 * kt + 4 * g);
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) kw[kt] = 0x01010101u;
+        }
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Ks, kt, 0), q0, zero4, 0, 0, 0);
@@ -1084,23 +1096,14 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); sum += st[kt][r]; }
         sum = col4_sum(sum);
         const float inv = 1.f / sum;
-        if (a.keep) {                                                // d softmax = keep scale * d(dropped weights)
-            int qi = 16 * qt + c;
-            qi = qi < a.N ? qi : a.N - 1;
-            const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                float m4[4];
-                keep4(kr + 16 * kt + 4 * g, a.kscale, m4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dp[kt][r] *= m4[r];
-            }
-        }
         float D = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kt][r] *= inv; D += st[kt][r] * dp[kt][r]; }
+            for (int r = 0; r < 4; ++r) {
+                dp[kt][r] *= ((kw[kt] >> (8 * r)) & 1u) ? a.kscale : 0.f;   // d softmax = keep scale * d(dropped weights); 1 when off
+                st[kt][r] *= inv; D += st[kt][r] * dp[kt][r];
+            }
         D = col4_sum(D);
         if (g == 0) { float* sp = stats + (16 * qt + c) * 3; sp[0] = m; sp[1] = inv; sp[2] = D; }
 #pragma unroll
@@ -1139,23 +1142,23 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
         const int ktok = sg.tok_k(16 * kt + c);
         const float mk = ktok >= 0 ? a.addmask[brow0 + ktok] : -INFINITY;
         f32x4 s2[NT], dp[NT];
+        uint32_t kw[NT];                                         // keepT bytes of (key 16 kt + c, queries 16 qt + 4 g .. + 3)
+        if (a.keepT) {
+            int kk = 16 * kt + c;
+            kk = kk < a.N ? kk : a.N - 1;
+            const uint8_t* kr = a.keepT + (((int64_t)b * a.H + h) * a.Ns + kk) * a.Ns;
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) kw[qt] = *(const uint32_t*)(kr + 16 * qt + 4 * g);
+        } else {
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) kw[qt] = 0x01010101u;
+        }
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt) {
             f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Qs, qt, 0), k0, zero4, 0, 0, 0);
             s2[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Qs, qt, 1), k1, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Gs, qt, 0), v0, zero4, 0, 0, 0);
             dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(Gs, qt, 1), v1, acc, 0, 0, 0);
-        }
-        float km[NT][4];
-        {
-            int kk = 16 * kt + c;
-            kk = kk < a.N ? kk : a.N - 1;
-            const uint8_t* kr = a.keepT ? a.keepT + (((int64_t)b * a.H + h) * a.Ns + kk) * a.Ns : nullptr;
-#pragma unroll
-            for (int qt = 0; qt < NT; ++qt) {
-                if (kr) keep4(kr + 16 * qt + 4 * g, a.kscale, km[qt]);
-                else { km[qt][0] = 1.f; km[qt][1] = 1.f; km[qt][2] = 1.f; km[qt][3] = 1.f; }
-            }
         }
         // row statistics of query q = 16 qt + 4 g + r (over ALL keys) come from layout 1 through LDS
 #pragma unroll
@@ -1166,9 +1169,9 @@ __global__ __launch_bounds__(256) void mattn_bwd_full_kernel(AttnArgs a) {
                 const bool qok = sg.tok_q(qi) >= 0;
                 const float* sp = stats + qi * 3;
                 const float p = qok ? __expf(s2[qt][r] * a.scale + mk - sp[0]) * sp[1] : 0.f;
-                s2[qt][r] = p;                                   // P[q][key]
-                dp[qt][r] = p * (dp[qt][r] * km[qt][r] - sp[2]); // dS[q][key]   (km: dropout multiplier, 1 when off)
-                s2[qt][r] *= km[qt][r];                          // dV takes the dropped weights
+                const float km = ((kw[qt] >> (8 * r)) & 1u) ? a.kscale : 0.f;   // dropout multiplier, 1 when off
+                dp[qt][r] = p * (dp[qt][r] * km - sp[2]);        // dS[q][key]
+                s2[qt][r] = p * km;                              // dV takes the dropped weights
             }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {

@@ -40,25 +40,36 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(int64_t n4, const T* _
     for (int t = 0; t < 4; ++t) dx[4 * i + t] = from_f<T>(((kb >> (8 * t)) & 1u) ? to_f(dy[4 * i + t]) * scale : 0.f);
 }
 
-// keep[bh][q][key] and keepT[bh][key][q] (row stride Ns = N rounded up to 16, pads 0): one thread per (bh, q, 4 keys)
+// keep[bh][q][key] and keepT[bh][key][q] (row stride Ns = N rounded up to 16, pads 0): one thread per 4 x 4 block (4 queries x 4
+// keys = 4 Philox calls), so both orientations leave as 4-byte words -- byte-wide scattered writes of the transposed copy cost 5x
 __global__ __launch_bounds__(256) void dropout_attn_mask_kernel(int64_t BH, int N, int Ns, uint8_t* __restrict__ keep, uint8_t* __restrict__ keepT,
                                                                 uint32_t thr, const uint32_t* __restrict__ state, uint32_t site) {
     const int ng = Ns / 4;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= BH * Ns * ng) return;
-    const int jg = (int)(idx % ng), q = (int)((idx / ng) % Ns);
-    const int64_t bh = idx / ((int64_t)ng * Ns);
-    uint32_t u[4] = {0u, 0u, 0u, 0u};
-    if (q < N) philox4x32_10((uint32_t)(bh * N + q), (uint32_t)jg, site, state[2], state[0], state[1], u);
-    uint32_t kb = 0;
+    if (idx >= BH * ng * ng) return;
+    const int jg = (int)(idx % ng), qg = (int)((idx / ng) % ng);
+    const int64_t bh = idx / ((int64_t)ng * ng);
+    const uint32_t off = state[2], s0 = state[0], s1 = state[1];
+    uint32_t kq[4], kt[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int j = 4 * jg + t;
-        const uint32_t k = (q < N && j < N && u[t] >= thr) ? 1u : 0u;
-        kb |= k << (8 * t);
-        keepT[(bh * Ns + j) * Ns + q] = (uint8_t)k;
+    for (int a = 0; a < 4; ++a) {
+        const int q = 4 * qg + a;
+        uint32_t u[4] = {0u, 0u, 0u, 0u};
+        if (q < N) philox4x32_10((uint32_t)(bh * N + q), (uint32_t)jg, site, off, s0, s1, u);
+        uint32_t kb = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t k = (q < N && 4 * jg + t < N && u[t] >= thr) ? 1u : 0u;
+            kb |= k << (8 * t);
+            kt[t] |= k << (8 * a);
+        }
+        kq[a] = kb;
     }
-    *(uint32_t*)(keep + (bh * Ns + q) * Ns + 4 * jg) = kb;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        *(uint32_t*)(keep + (bh * Ns + 4 * qg + a) * Ns + 4 * jg) = kq[a];
+        *(uint32_t*)(keepT + (bh * Ns + 4 * jg + a) * Ns + 4 * qg) = kt[a];
+    }
 }
 
 static inline uint32_t drop_threshold(float p) { const double t = (double)p * 4294967296.0; return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t; }
@@ -100,7 +111,7 @@ extern "C" int dvlp_dropout_attn_mask(int64_t BH, int64_t N, float p, const void
     dvlp_clear_status();
     if (BH <= 0 || N <= 0 || p < 0.f || p >= 1.f) return DVLP_ERR_SHAPE;
     const int Ns = (int)((N + 15) / 16 * 16);
-    const int64_t total = BH * Ns * (Ns / 4);
+    const int64_t total = BH * (Ns / 4) * (Ns / 4);
     hipLaunchKernelGGL(dropout_attn_mask_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, BH, (int)N, Ns, (uint8_t*)keep,
                        (uint8_t*)keepT, drop_threshold(p), (const uint32_t*)state, (uint32_t)site);
     return dvlp_launch_status();
