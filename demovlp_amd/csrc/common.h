@@ -120,6 +120,34 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
     return fmaf(x * 0.39894228040143267794f, E, Phi);
 }
 
+// Polynomial forms for the 256-row bf16 GEMM epilogue, two elements at a time (v_pk_fma_f32): the transcendental form above is
+// 2 quarter-rate + ~14 full-rate VALU instructions per element, and with one workgroup per CU nothing overlaps them -- the fc1
+// forward / fc2 backward products spent ~25 % of their time there.  Odd minimax polynomials in z = clamp(x / A, -1, 1)
+// (tools/fit_gelu_poly.py, errors include the fp32 Horner evaluation):
+//   Phi(x)   = 0.5 + z P(z^2), A = 4.0, |err| <= 6e-6 inside [-4, 4] (gelu: 2.3e-5), tails pinned at Phi(+-4)
+//   gelu'(x) = 0.5 + z Q(z^2), A = 4.5, |err| <= 1.8e-4
+// both far below the bf16 resolution of the values they produce.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float GELU_PHI_C[9] = {1.595690840e+00f, -4.250278161e+00f, 1.011453720e+01f, -1.857818477e+01f, 2.592817434e+01f, -2.640316869e+01f, 1.822784375e+01f, -7.519930336e+00f, 1.385288103e+00f};
+constexpr float GELU_DGELU_C[10] = {3.589317633e+00f, -2.414135244e+01f, 1.081506568e+02f, -3.294218669e+02f, 7.116908195e+02f, -1.091321666e+03f, 1.154870954e+03f, -7.967612061e+02f, 3.208072879e+02f, -5.696292942e+01f};
+template <int NC>
+__device__ __forceinline__ f32x2 odd_poly2(const float (&c)[NC], f32x2 z) {
+    const f32x2 s = z * z;
+    f32x2 acc = {c[NC - 1], c[NC - 1]};
+#pragma unroll
+    for (int k = NC - 2; k >= 0; --k) acc = __builtin_elementwise_fma(acc, s, (f32x2){c[k], c[k]});
+    return __builtin_elementwise_fma(z, acc, (f32x2){0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    const f32x2 z = {__builtin_amdgcn_fmed3f(x[0] * 0.25f, -1.f, 1.f), __builtin_amdgcn_fmed3f(x[1] * 0.25f, -1.f, 1.f)};
+    return x * odd_poly2(GELU_PHI_C, z);
+}
+__device__ __forceinline__ f32x2 gelu_grad_poly2(f32x2 x) {
+    constexpr float ia = 1.f / 4.5f;
+    const f32x2 z = {__builtin_amdgcn_fmed3f(x[0] * ia, -1.f, 1.f), __builtin_amdgcn_fmed3f(x[1] * ia, -1.f, 1.f)};
+    return odd_poly2(GELU_DGELU_C, z);
+}
+
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so a dropout mask is a
 // pure function of (seed, step offset, site, element index) -- reproducible on the host (oracle/restatement.py:philox4x32_10,
 // pinned by the published known-answer vectors) and independent of launch geometry.

@@ -121,36 +121,42 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
 
 // epi_store8 for a whole, aligned 8-column group with the operands it would load (bias, residual, aux-in) already in
 // registers: the 256-row kernel runs one workgroup per CU, so nothing hides a dependent load inside its store loop.
-__device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n, float (&v)[8],
-                                               const float4 b0, const float4 b1, const bf16x8 r, const bf16x8 a) {
+// `fl` / `has_res` are e.flags / (e.res != null), or compile-time constants in the kernels specialised on the epilogue kind.
+__device__ __forceinline__ void epi_store8_pre(const Epi& e, const int fl, const bool has_res, bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n,
+                                               float (&v)[8], const float4 b0, const float4 b1, const bf16x8 r, const bf16x8 a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] *= e.alpha;
     if (e.bias) { v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
-    if (e.flags & EPI_GELU) {
+    if (fl & EPI_GELU) {
         bf16x8 pre;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_fast(v[t]); }
+        for (int t = 0; t < 8; ++t) pre[t] = (bf16)v[t];
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) { const f32x2 y = gelu_poly2((f32x2){v[t], v[t + 1]}); v[t] = y[0]; v[t + 1] = y[1]; }
         __builtin_nontemporal_store(pre, (bf16x8*)((bf16*)e.aux + m * e.ldaux + n));
     }
-    if (e.flags & EPI_LEAKY) {
+    if (fl & EPI_LEAKY) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] = v[t] > 0.f ? v[t] : 0.1f * v[t];
     }
-    if (e.flags & EPI_GELU_BWD) {
+    if (fl & EPI_GELU_BWD) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] *= gelu_fast_grad((float)a[t]);
+        for (int t = 0; t < 8; t += 2) {
+            const f32x2 d = gelu_grad_poly2((f32x2){(float)a[t], (float)a[t + 1]});
+            v[t] *= d[0]; v[t + 1] *= d[1];
+        }
     }
-    if (e.flags & EPI_RELU_BWD) {
+    if (fl & EPI_RELU_BWD) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] = (float)a[t] > 0.f ? v[t] : 0.f;
     }
-    if (e.res) {
+    if (has_res) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] += (float)r[t];
     }
-    if (e.flags & EPI_OUT_F32) {
+    if (fl & EPI_OUT_F32) {
         float* Cf = (float*)C + m * ldc + n;
-        if (e.flags & EPI_ACCUM) {
+        if (fl & EPI_ACCUM) {
             const float4 c0 = *(const float4*)Cf, c1 = *(const float4*)(Cf + 4);
             v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
         }
@@ -159,7 +165,7 @@ __device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ 
         return;
     }
     bf16* Cp = C + m * ldc + n;
-    if (e.flags & EPI_ACCUM) {
+    if (fl & EPI_ACCUM) {
         const bf16x8 c = *(const bf16x8*)Cp;
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] += (float)c[t];
@@ -169,7 +175,8 @@ __device__ __forceinline__ void epi_store8_pre(const Epi& e, bf16* __restrict__ 
     for (int t = 0; t < 8; ++t) { o[t] = (bf16)v[t]; v[t] = (float)o[t]; }     // v <- the values as stored (column-sum fusion)
     // streaming store: a 256 x 256 tile's outputs (128-256 KB per CU per round) would otherwise push the operand panels that the
     // neighbouring column tiles are about to re-read out of the 4 MiB L2
-    __builtin_nontemporal_store(o, (bf16x8*)Cp);
+    if (fl & (64 << 24)) *(bf16x8*)Cp = o;            // timing ablation: ordinary store
+    else __builtin_nontemporal_store(o, (bf16x8*)Cp);
 }
 
 // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of tiles
@@ -839,7 +846,11 @@ __device__ __attribute__((noinline)) void p8_store_ragged(const Epi& e, bf16* __
 }
 
 // One 256 x 256 output tile at (m0, n0) over K tiles [kbeg, kbeg + 64 nk); `slab_out` non-null: raw fp32 partial (split-K).
-template <bool A_R, bool B_R>
+// EK = epilogue kind of whole tiles: 0 bias only, 1 bias + residual, 2 GELU forward (pre-activation out), 3 GELU backward
+// (pre-activation in), 4 anything (flags read at run time).  Kinds 0-3 are straight-line code: with run-time flag tests around the
+// residual / aux loads the compiler closes every step with s_waitcnt vmcnt(0), which also waits for the previous step's stores.
+constexpr int P8_EK_ANY = 4;
+template <bool A_R, bool B_R, int EK>
 __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                         int64_t ldb, bf16* __restrict__ C, int64_t ldc, const Epi& e, int64_t m0, int64_t n0, int64_t kbeg, int nk,
                                         float* __restrict__ slab_out) {
@@ -989,7 +1000,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[s][i], (NJ ? bH : bL)[s][j], acc[MI + i][NJ + j], 0, 0, 0);
+                    acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((NJ ? bH : bL)[s][j], aF[s][i], acc[MI + i][NJ + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -1006,89 +1017,116 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                 // re-align the groups: every LDS read and DMA has retired
 
-    // Epilogue, per wave and without workgroup barriers: four 32-row passes (rows {lo, hi} x {first, second 32}); a pass
-    // covers the wave's 32 + 32 columns.  Accumulators go through LDS for 16-byte stores.  One workgroup per CU means no
-    // other wave hides a load inside the store loop, so the residual / aux-in rows of pass p + 1 are fetched (8 loads in
-    // flight) while pass p is stored, and parked in LDS so that the store loop stays a rolled loop.
-    constexpr int P_EPW = 32 * 68 * 4 + 2 * 4096;              // bytes per wave: staged accumulators + residual + aux-in rows
-    float* Ct = (float*)(smem_raw + wid * P_EPW);
-    bf16x8* Rs = (bf16x8*)(smem_raw + wid * P_EPW + 32 * 68 * 4);
-    bf16x8* As = Rs + 256;
-    const int ab = e.flags >> 24;                      // timing ablations (0 in production): 8 no stores, 16 no epilogue
+    // Epilogue, per wave and without workgroup barriers.  The products above are issued with the B fragment as the FIRST MFMA
+    // operand, so the accumulator tile is C^T: lane (g = lane / 16, r = lane % 16) holds acc[i][j][0..3] = C[row 16 i' + r][columns
+    // 16 j' + 4 g + 0..3] -- four CONSECUTIVE columns of one row.  fp32 outputs (split-K slabs) leave as 16-byte stores as they are;
+    // for bf16 one v_permlane16_swap per register pairs the two 16-column blocks so that a lane owns 8 consecutive columns
+    // (16 bytes) and a store instruction writes 16 rows x 64 contiguous bytes.  No LDS round trip (it was ~20 % of a K = 768 product).
+    const int ab = e.flags >> 24;    // timing ablations (0 in production): 8 no stores, 16 no epilogue, 32 stores hit 256 rows only, 64 no nt
     if (ab & 16) { if (acc[0][0][0] == 123.456f && acc[7][3][3] == 1.f) C[0] = (bf16)1.f; return; }
     if (ab & 8) M = 0;
-    const int col = (lane & 7) * 8, rsub = lane >> 3;
-    const int64_t ncol = n0 + 32 * wc + (col < 32 ? col : 96 + col);
-    const bool whole = e.vec && n0 + 256 <= N && !slab_out;   // every 8-column group of this block is whole and 16-byte aligned
-    const bool has_res = e.res != nullptr, has_aux = (e.flags & (EPI_GELU_BWD | EPI_RELU_BWD)) != 0;
-    float4 bb0 = make_float4(0.f, 0.f, 0.f, 0.f), bb1 = bb0;
-    if (whole && e.bias) { bb0 = *(const float4*)(e.bias + ncol); bb1 = *(const float4*)(e.bias + ncol + 4); }
-    bf16x8 pr[4], pa[4];
-    float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // e.csum: this lane's column sums over the rows it stores
-    auto mrow_of = [&](int hp) { return m0 + 128 * (hp >> 1) + 64 * wr + 32 * (hp & 1); };
-    auto preload = [&](int hp) {
-        if (!whole) return;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    auto row_of = [&](int ii) { return m0 + 128 * (ii >> 2) + 64 * wr + 16 * (ii & 3) + r16; };
+    if (slab_out && n0 + 256 <= N && (N & 3) == 0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int64_t m = mrow_of(hp) + it * 8 + rsub;
-            m = m < M ? m : (M > 0 ? M - 1 : 0);
-            if (has_res) pr[it] = *(const bf16x8*)((const bf16*)e.res + m * e.ldres + ncol);
-            if (has_aux) pa[it] = *(const bf16x8*)((const bf16*)e.aux + m * e.ldaux + ncol);
+        for (int ii = 0; ii < 8; ++ii) {
+            const int64_t m = row_of(ii);
+            if (m < M) {
+                float* dst = slab_out + m * N + n0 + 32 * wc + 4 * g4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(f32x4*)(dst + 128 * (j >> 1) + 16 * (j & 1)) = acc[ii][j];
+            }
         }
-    };
-    preload(0);
+        return;
+    }
+    const bool whole = e.vec && n0 + 256 <= N && !slab_out;   // every 8-column group of this block is whole and 16-byte aligned
+    if (whole) {
+        const int fl = EK == P8_EK_ANY ? e.flags : EK == 2 ? EPI_GELU : EK == 3 ? EPI_GELU_BWD : 0;
+        const bool has_res = EK == P8_EK_ANY ? e.res != nullptr : EK == 1, has_aux = (fl & (EPI_GELU_BWD | EPI_RELU_BWD)) != 0;
+        const int64_t cn0 = n0 + 32 * wc + 16 * (g4 & 1) + 8 * (g4 >> 1);      // + 128 hh: this lane's 8 columns after the swap
+        float4 bb[2][2];
 #pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            bb[hh][0] = make_float4(0.f, 0.f, 0.f, 0.f); bb[hh][1] = bb[hh][0];
+            if (e.bias) { bb[hh][0] = *(const float4*)(e.bias + cn0 + 128 * hh); bb[hh][1] = *(const float4*)(e.bias + cn0 + 128 * hh + 4); }
+        }
+        float cs[2][8];                                    // e.csum: this lane's column sums over the rows it stores
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cs[hh][t] = 0.f;
+        // residual / aux-in rows are requested three row blocks ahead: one workgroup per CU means no other wave hides a dependent
+        // load, and vmcnt retires in issue order, so a load waits for every store issued before it
+        bf16x8 pr[4][2] = {}, pa[4][2] = {};
+        auto preload = [&](int ii, bf16x8 (&r)[2], bf16x8 (&a)[2]) {
+            int64_t m = row_of(ii);
+            m = m < M ? m : (M > 0 ? M - 1 : 0);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (has_res) r[hh] = *(const bf16x8*)((const bf16*)e.res + m * e.ldres + cn0 + 128 * hh);
+                if (has_aux) a[hh] = *(const bf16x8*)((const bf16*)e.aux + m * e.ldaux + cn0 + 128 * hh);
+            }
+        };
+        preload(0, pr[0], pa[0]); preload(1, pr[1], pa[1]); preload(2, pr[2], pa[2]);
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            if (ii < 5) preload(ii + 3, pr[(ii + 3) & 3], pa[(ii + 3) & 3]);
+            const int64_t m = row_of(ii);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * hh][t]), __float_as_uint(acc[ii][2 * hh + 1][t]), false, false);
+                    v[t] = __uint_as_float(sw[0]); v[4 + t] = __uint_as_float(sw[1]);
+                }
+                if (m < M) {
+                    epi_store8_pre(e, fl, has_res, C, ldc, (EK == P8_EK_ANY && (ab & 32)) ? (m & 255) : m, cn0 + 128 * hh, v, bb[hh][0], bb[hh][1], pr[ii & 3][hh], pa[ii & 3][hh]);
+                    if (e.csum) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) cs[hh][t] += v[t];
+                    }
+                }
+            }
+        }
+        if (e.csum) {
+            // the 16 lanes of a row group hold the same 8 columns for different rows: combine, one partial row per wave
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) cs[hh][t] = row16_sum(cs[hh][t]);
+                if (r16 == 0) {
+                    float* dst = e.csum + ((m0 >> 8) * 2 + wr) * N + cn0 + 128 * hh;
+                    *(float4*)dst = make_float4(cs[hh][0], cs[hh][1], cs[hh][2], cs[hh][3]);
+                    *(float4*)(dst + 4) = make_float4(cs[hh][4], cs[hh][5], cs[hh][6], cs[hh][7]);
+                }
+            }
+        }
+        return;
+    }
+    // ragged tiles / unaligned outputs: four 32-row passes through LDS (rows {lo, hi} x {first, second 32}; a pass covers the
+    // wave's 32 + 32 columns), scalar epilogue out of line
+    constexpr int P_EPW = 32 * 68 * 4;                         // bytes per wave: staged accumulators
+    float* Ct = (float*)(smem_raw + wid * P_EPW);
+    const int col = (lane & 7) * 8;
+    const int64_t ncol = n0 + 32 * wc + (col < 32 ? col : 96 + col);
+    auto mrow_of = [&](int hp) { return m0 + 128 * (hp >> 1) + 64 * wr + 32 * (hp & 1); };
+#pragma unroll 1
     for (int hp = 0; hp < 4; ++hp) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) Ct[(16 * i + 4 * (lane >> 4) + rr) * 68 + 16 * j + (lane & 15)] = acc[2 * hp + i][j][rr];
-        const int64_t mrow0 = mrow_of(hp);
-        if (whole) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (has_res) Rs[it * 64 + lane] = pr[it];
-                if (has_aux) As[it * 64 + lane] = pa[it];
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t4 = hp == 0 ? acc[i][j] : hp == 1 ? acc[2 + i][j] : hp == 2 ? acc[4 + i][j] : acc[6 + i][j];
+                *(f32x4*)&Ct[(16 * i + r16) * 68 + 16 * j + 4 * g4] = t4;
             }
-            if (hp < 3) preload(hp + 1);
-#pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + rsub;
-                const int64_t m = mrow0 + row;
-                const float4 c0 = *(const float4*)&Ct[row * 68 + col], c1 = *(const float4*)&Ct[row * 68 + col + 4];
-                float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                bf16x8 r = {}, a = {};
-                if (has_res) r = Rs[it * 64 + lane];
-                if (has_aux) a = As[it * 64 + lane];
-                if (m < M) {
-                    epi_store8_pre(e, C, ldc, m, ncol, v, bb0, bb1, r, a);
-                    if (e.csum) {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) cs8[t] += v[t];
-                    }
-                }
-            }
-        } else {
-            const Epi ec = e;   // see epi_store8: keep the kernel's own Epi out of scratch
-            p8_store_ragged(ec, C, ldc, Ct, mrow0, ncol, M, N, slab_out, lane);
-        }
-    }
-    if (e.csum && whole) {
-        // the eight lanes that share lane & 7 hold the same 8 columns for different rows: combine, one partial row per wave
-#pragma unroll
-        for (int t = 0; t < 8; ++t) cs8[t] = stride8_sum(cs8[t]);
-        if (rsub == 0) {
-            float* dst = e.csum + ((m0 >> 8) * 2 + wr) * N + ncol;
-            *(float4*)dst = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
-            *(float4*)(dst + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
-        }
+        const Epi ec = e;   // see epi_store8: keep the kernel's own Epi out of scratch
+        p8_store_ragged(ec, C, ldc, Ct, mrow_of(hp), ncol, M, N, slab_out, lane);
     }
 }
-constexpr int P_EPI_LDS = 8 * (32 * 68 * 4 + 2 * 4096);
+constexpr int P_EPI_LDS = 8 * (32 * 68 * 4);
 
-template <bool A_R, bool B_R>
+template <bool A_R, bool B_R, int EK>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
                                                            const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
                                                            Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
@@ -1101,7 +1139,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
     if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
     const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
-    p8_tile<A_R, B_R>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
+    p8_tile<A_R, B_R, EK>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
 }
 
 // Grouped weight gradients: up to P8G_MAX independent dW_p = dY_p^T X_p products (all form R x form R, fp32 out) in ONE
@@ -1136,7 +1174,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_group_kernel(P8Group g, int 
     Epi e{nullptr, nullptr, nullptr, 0, 0, flags | EPI_OUT_F32, 1.0f, 0, 0, 0, 0, 0, 1, nullptr};
     e.vec = (g.N[p] % 4 == 0) ? 1 : 0;
     float* slab_out = g.S[p] > 1 ? g.slab[p] + (int64_t)z * g.M[p] * g.N[p] : nullptr;
-    p8_tile<true, true>(smem_raw, g.M[p], g.N[p], g.A[p], g.lda[p], g.B[p], g.ldb[p], (bf16*)g.C[p], g.N[p], e, tm_ * 256, tn_ * 256, kbeg,
+    p8_tile<true, true, P8_EK_ANY>(smem_raw, g.M[p], g.N[p], g.A[p], g.lda[p], g.B[p], g.ldb[p], (bf16*)g.C[p], g.N[p], e, tm_ * 256, tn_ * 256, kbeg,
                         (int)((kend - kbeg) / H_BK), slab_out);
 }
 // sums the slabs of every split problem of a group into its fp32 destination (float4 per thread)
@@ -1368,10 +1406,12 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
         hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
-#define LAUNCH_P8_(AR, BR) do { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AR, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
-        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
+#define LAUNCH_P8K_(AR, BR, EK) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AR, BR, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR, EK>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn8, kchunk, slab); } while (0)
+#define LAUNCH_P8_(AR, BR) do { if (ek8 == 0) LAUNCH_P8K_(AR, BR, 0); else if (ek8 == 1) LAUNCH_P8K_(AR, BR, 1); else if (ek8 == 2) LAUNCH_P8K_(AR, BR, 2); \
+        else if (ek8 == 3) LAUNCH_P8K_(AR, BR, 3); else LAUNCH_P8K_(AR, BR, P8_EK_ANY); } while (0)
 #define LAUNCH_GLDS_(AR, BR) do { if (p8) LAUNCH_P8_(AR, BR); else if (wide) { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128); } \
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4, 3>), gridw, dim3(512), (size_t)3 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
@@ -1384,6 +1424,9 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         const bool wide = dma && !p8 && g_wide_mode != 0 && (g_wide_mode == 2 || ntm_w * ntn * batch * S >= 512);
         dim3 gridw((unsigned)(ntm_w * ntn), (unsigned)batch, (unsigned)S);
         dim3 grid8((unsigned)(ntm8 * ntn8), (unsigned)batch, (unsigned)S);
+        // epilogue kind of the 256-row kernel (see p8_tile)
+        const int fmask8 = flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD | EPI_ACCUM | EPI_OUT_F32 | EPI_LEAKY);
+        const int ek8 = g_ablate ? P8_EK_ANY : fmask8 == 0 ? (res ? 1 : 0) : (fmask8 == EPI_GELU && !res) ? 2 : (fmask8 == EPI_GELU_BWD && !res) ? 3 : P8_EK_ANY;
 #define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         rec.kern = p8 ? 2 : dma ? 1 : 0;
         if (!transA && !transB) LAUNCH_BF16(false, false);

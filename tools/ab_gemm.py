@@ -64,4 +64,4 @@ for label, ta, tb, M, N, K, epi in CASES:
             times[k].append(a.elapsed_time(b) * 100)
     m = {k: statistics.median(v) for k, v in times.items()}
     same = torch.equal(outs["new"], outs["prev"])
-    print(f"{label:14s} M={M} N={N} K={K}: prev {m['prev']:7.1f} us  new {m['new']:7.1f} us  ({100 * (m['prev'] / m['new'] - 1):+5.1f} %)  bit-equal={same}")
+    print(f"{label:14s} M={M} N={N} K={K}: prev {m['prev']:7.1f} us  new {m['new']:7.1f} us  ({100 * (m['prev'] / m['new'] - 1):+5.1f} %)  bit-equal={same} max|d|={(outs['new'].float() - outs['prev'].float()).abs().max().item():.3g}")
