@@ -32,7 +32,9 @@ template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v
 // ds_bpermute-based __shfl_xor ladder these replace cost six dependent LDS round trips.
 template <int CTRL>
 __device__ __forceinline__ float dvlp_dpp(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
+    // old = 0 with bound_ctrl: every pattern used here has a valid source for every lane, and in this form the compiler folds the
+    // move into the consuming add (v_add_f32_dpp) instead of emitting v_mov_b32_dpp + v_add_f32
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float wave_sum(float v) {
     v += dvlp_dpp<0xB1>(v);      // quad_perm [1,0,3,2]

@@ -131,6 +131,7 @@ struct PairArgs {
     int Bi, Bj, G, W, Gp, Wp, Wq;
     float lam;
     int gate;
+    int stop;                     // timing ablation (0 in production): leave the backward kernel after stage `stop`
 };
 
 constexpr int XT = 1024;     // threads per pair workgroup: 16 waves share one S_ij tile (the tile caps residency at 1 block/CU)
@@ -211,18 +212,24 @@ __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, flo
 
 // softmax over n entries spread over a lane group (FULL = 64 lanes, else a 32-lane half); e[k] is the entry of lane-slot
 // idx = lid + STRIDE*k.  Returns P (pre-gate) in e, P' (gated, renormalised) in pp, s = sum of gated P.
-template <int NK, bool FULL>
-__device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], int n, int lid, int gate, float& s_out) {
+// FAST (the bf16 kernels): the entries are lambda (A + mask) with |A| <= 1 and mask <= 0, so `bound` = |lambda| replaces the
+// max pass (one cross-lane reduction and a compare chain per row; exp(e - bound) >= exp(-2 lambda) stays normal), and the two
+// reciprocals are v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division.  The fp32 kernels keep both exact.
+template <int NK, bool FULL, bool FAST>
+__device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], int n, int lid, int gate, float bound, float& s_out) {
     constexpr int STRIDE = FULL ? 64 : 32;
-    float m = -INFINITY;
+    float m = bound;
+    if (!FAST) {
+        m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) m = fmaxf(m, lid + STRIDE * k < n ? e[k] : -INFINITY);
-    m = FULL ? wave_max(m) : half_max(m);
+        for (int k = 0; k < NK; ++k) m = fmaxf(m, lid + STRIDE * k < n ? e[k] : -INFINITY);
+        m = FULL ? wave_max(m) : half_max(m);
+    }
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < NK; ++k) { e[k] = lid + STRIDE * k < n ? __expf(e[k] - m) : 0.f; sum += e[k]; }
     sum = FULL ? wave_sum(sum) : half_sum(sum);
-    const float inv = 1.f / sum;
+    const float inv = FAST ? __builtin_amdgcn_rcpf(sum) : 1.f / sum;
     float psum = 0.f;
 #pragma unroll
     for (int k = 0; k < NK; ++k) { e[k] = e[k] * inv; psum += e[k]; }
@@ -235,7 +242,7 @@ __device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], i
         s += pp[k];
     }
     s = FULL ? wave_sum(s) : half_sum(s);
-    const float is = 1.f / s;
+    const float is = FAST ? __builtin_amdgcn_rcpf(s) : 1.f / s;
 #pragma unroll
     for (int k = 0; k < NK; ++k) pp[k] = pp[k] * is;
     s_out = s;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
         if (w < a.W) {
 #pragma unroll
             for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] * ri[k] + mi[k]) : 0.f; }
-            focal_softmax<NKG, true>(e, pp, a.G, lane, a.gate, s);
+            focal_softmax<NKG, true, sizeof(T) == 2>(e, pp, a.G, lane, a.gate, fabsf(a.lam), s);
         } else {
 #pragma unroll
             for (int k = 0; k < NKG; ++k) pp[k] = 0.f;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
         float e[NKW], pp[NKW], s;
 #pragma unroll
         for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; e[k] = w < a.W ? a.lam * (Ssm[gc * a.Wq + w] * ci[k] + mc[k]) : 0.f; }
-        focal_softmax<NKW, false>(e, pp, a.W, hl, a.gate, s);
+        focal_softmax<NKW, false, sizeof(T) == 2>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
         if (ok) {
 #pragma unroll
             for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
             float e[NKG], pp[NKG], sv[NKG], s;
 #pragma unroll
             for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; sv[k] = g < a.G ? Ssm[g * a.Wq + w] : 0.f; e[k] = a.lam * (sv[k] * ri[k] + mi[k]); }
-            focal_softmax<NKG, true>(e, pp, a.G, lane, a.gate, s);
+            focal_softmax<NKG, true, sizeof(T) == 2>(e, pp, a.G, lane, a.gate, fabsf(a.lam), s);
             float dpp[NKG], d1 = 0.f;
 #pragma unroll
             for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; dpp[k] = g < a.G ? to_f(D1[(int64_t)w * a.Gp + g]) : 0.f; d1 += dpp[k] * pp[k]; }
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
             float e[NKW], pp[NKW], sv[NKW], s;
 #pragma unroll
             for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = a.lam * (sv[k] * ci[k] + mc[k]); }
-            focal_softmax<NKW, false>(e, pp, a.W, hl, a.gate, s);
+            focal_softmax<NKW, false, sizeof(T) == 2>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
             float dpp[NKW], d1 = 0.f;
 #pragma unroll
             for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; dpp[k] = w < a.W ? to_f(D2[(int64_t)gc * a.Wp + w]) : 0.f; d1 += dpp[k] * pp[k]; }
@@ -409,6 +416,167 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_kernel(PairArgs a) {
             }
         }
         __syncthreads();
+    }
+}
+
+// bf16 form of the backward above.  S is bf16 in memory, so its fp32 copy in the LDS tile has 16 free low bits per element:
+// the image->text pass parks its result dA r (bf16, exactly what the generic kernel stores to global memory) there, the
+// text->image results stay in registers (the last pass walks the same rows), and the only global traffic left is S, dP1, dP2
+// in and dS out -- the generic kernel additionally writes both intermediate tiles and reads them back through a 64-row
+// transpose tile (ten workgroup barriers with a memory round trip behind each).  dP1 / dP2 rows are requested ahead of the
+// phases that use them: one workgroup per CU, nothing else hides the latency.
+template <int NKG, int NKW>
+__global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    constexpr int NW = XT / 64, IT1 = 2 * NKW, IT2 = 2 * NKG;       // words per wave (<= W / 16), row pairs per wave (<= G / 32)
+    const int j = blockIdx.x, i = blockIdx.y;
+    float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* cpart = cn + a.W;
+    float* rowdot = cpart + 8 * a.W; float* coldot = rowdot + a.G;
+    float* rpart = coldot + a.W;                // [NW][G]        per-wave partial <dA, S> over the words the wave owned
+    float* qpart = rpart + NW * a.G;            // [2 NW][32 NKW] per-half partial <dA2, S> over the regions the half owned
+    const bf16* D1 = (const bf16*)a.dP1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;
+    const bf16* D2 = (const bf16*)a.dP2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;
+    // prefetched rows stay packed (two bf16 per register) until their pass: unpacked they would not fit 128 VGPRs
+    const unsigned short* D1u = (const unsigned short*)D1; const unsigned short* D2u = (const unsigned short*)D2;
+    auto unpack = [](const uint32_t* p, int k) { return __uint_as_float((k & 1) ? (p[k >> 1] & 0xffff0000u) : (p[k >> 1] << 16)); };
+    uint32_t d1p[IT1][(NKG + 1) / 2];
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = wid + NW * it;
+#pragma unroll
+        for (int k = 0; k < NKG; k += 2) {
+            const int g0 = lane + 64 * k, g1 = g0 + 64;
+            const uint32_t lo = (w < a.W && g0 < a.G) ? D1u[(int64_t)w * a.Gp + g0] : 0u;
+            const uint32_t hi = (k + 1 < NKG && w < a.W && g1 < a.G) ? D1u[(int64_t)w * a.Gp + g1] : 0u;
+            d1p[it][k >> 1] = lo | (hi << 16);
+        }
+    }
+    pair_load_S<bf16>(a, i, j, Ssm, rn, cn, cpart);
+    if (a.stop == 1) { if (d1p[0][0] == 0x12345678u) rn[0] = 1.f; return; }
+    const float* mimg = a.mimg + (int64_t)i * a.G;
+    const float* mcap = a.mcap + (int64_t)j * a.W;
+    float d2v[IT2][NKW];                        // dA2 c of the rows this half owns, for the last pass
+    uint32_t* Su = (uint32_t*)Ssm;
+    {
+        float mi[NKG], ri[NKG], rd[NKG];
+#pragma unroll
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; mi[k] = g < a.G ? mimg[g] : 0.f; ri[k] = g < a.G ? rn[g] : 0.f; rd[k] = 0.f; }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int w = wid + NW * it;
+            if (w >= a.W) break;
+            float e[NKG], pp[NKG], sv[NKG], s;
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; sv[k] = g < a.G ? Ssm[g * a.Wq + w] : 0.f; e[k] = a.lam * (sv[k] * ri[k] + mi[k]); }
+            focal_softmax<NKG, true, true>(e, pp, a.G, lane, a.gate, fabsf(a.lam), s);
+            float dpp[NKG], d1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) { dpp[k] = unpack(d1p[it], k); d1 += dpp[k] * pp[k]; }
+            d1 = wave_sum(d1);
+            const float is = __builtin_amdgcn_rcpf(s);
+            float d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) * is : 0.f; d2 += dpp[k] * e[k]; }
+            d2 = wave_sum(d2);
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) {
+                const int g = lane + 64 * k;
+                const float dA = a.lam * e[k] * (dpp[k] - d2);           // softmax backward, times lambda
+                if (g < a.G) Su[g * a.Wq + w] = __float_as_uint(sv[k]) | (uint32_t)__builtin_bit_cast(unsigned short, (bf16)(dA * ri[k]));
+                rd[k] += dA * sv[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.G) rpart[wid * a.G + g] = rd[k]; }
+    }
+    if (a.stop == 2) return;
+    uint32_t d2p[IT2][(NKW + 1) / 2];
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+        const int g = 2 * wid + half + 2 * NW * it;
+#pragma unroll
+        for (int k = 0; k < NKW; k += 2) {
+            const int w0 = hl + 32 * k, w1 = w0 + 32;
+            const uint32_t lo = (g < a.G && w0 < a.W) ? D2u[(int64_t)g * a.Wp + w0] : 0u;
+            const uint32_t hi = (k + 1 < NKW && g < a.G && w1 < a.W) ? D2u[(int64_t)g * a.Wp + w1] : 0u;
+            d2p[it][k >> 1] = lo | (hi << 16);
+        }
+    }
+    {
+        constexpr int W32 = 32 * NKW;
+        float mc[NKW], ci[NKW], cd[NKW];
+#pragma unroll
+        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; cd[k] = 0.f; }
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const int g = 2 * wid + half + 2 * NW * it;
+            if (2 * wid + 2 * NW * it >= a.G) break;                     // wave-uniform: both halves past the last region
+            const bool ok = g < a.G;
+            const int gc = ok ? g : a.G - 1;
+            float e[NKW], pp[NKW], sv[NKW], s;
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) {
+                const int w = hl + 32 * k;
+                sv[k] = w < a.W ? __uint_as_float(Su[gc * a.Wq + w] & 0xffff0000u) : 0.f;
+                e[k] = a.lam * (sv[k] * ci[k] + mc[k]);
+            }
+            focal_softmax<NKW, false, true>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
+            float dpp[NKW], d1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) { dpp[k] = unpack(d2p[it], k); d1 += dpp[k] * pp[k]; }
+            d1 = half_sum(d1);
+            const float is = __builtin_amdgcn_rcpf(s);
+            float d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) { dpp[k] = pp[k] > 0.f ? (dpp[k] - d1) * is : 0.f; d2 += dpp[k] * e[k]; }
+            d2 = half_sum(d2);
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) {
+                const float dA = ok ? a.lam * e[k] * (dpp[k] - d2) : 0.f;
+                d2v[it][k] = dA * ci[k];
+                cd[k] += dA * sv[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + hl + 32 * k] = cd[k];
+    }
+    if (a.stop == 3) { if (d2v[0][0] == 123.456f) rn[0] = 1.f; return; }
+    __syncthreads();
+    for (int g = threadIdx.x; g < a.G; g += XT) {
+        float t = 0.f;
+        for (int k = 0; k < NW; ++k) t += rpart[k * a.G + g];
+        const float r = rn[g];
+        rowdot[g] = t * r * r / fmaxf(1.f / r - 1e-8f, 1e-30f);
+    }
+    for (int w = threadIdx.x; w < a.W; w += XT) {
+        float t = 0.f;
+        for (int k = 0; k < 2 * NW; ++k) t += qpart[k * 32 * NKW + w];
+        const float c = cn[w];
+        coldot[w] = t * c * c / fmaxf(1.f / c - 1e-8f, 1e-30f);
+    }
+    __syncthreads();
+    // A = S r with r = 1 / (|S_row| + eps):  dS = dA r - S <dA,S>_row r^2 / (1/r - eps); same along columns; then LeakyReLU'
+    bf16* S = (bf16*)a.S;
+    float cc[NKW];
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; cc[k] = w < a.W ? coldot[w] : 0.f; }
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+        const int g = 2 * wid + half + 2 * NW * it;
+        if (g >= a.G) break;
+        const float cr = rowdot[g];
+        bf16* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
+#pragma unroll
+        for (int k = 0; k < NKW; ++k) {
+            const int w = hl + 32 * k;
+            if (w < a.W) {
+                const uint32_t u = Su[g * a.Wq + w];
+                const float sv = __uint_as_float(u & 0xffff0000u), d1r = __uint_as_float(u << 16);
+                const float ds = d1r + d2v[it][k] - sv * (cr + cc[k]);
+                row[w] = (bf16)(sv > 0.f ? ds : 0.1f * ds);
+            }
+        }
     }
 }
 
@@ -562,7 +730,7 @@ __global__ __launch_bounds__(256) void xg_t2i_kernel(GenArgs a) {
         float sv[4], e[4], pp[4], s;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int w = hl + 32 * k; sv[k] = w < p.W ? to_f(row[w]) : 0.f; e[k] = p.lam * (sv[k] * ci[k] + mc[k]); }
-        focal_softmax<4, false>(e, pp, p.W, hl, p.gate, s);
+        focal_softmax<4, false, false>(e, pp, p.W, hl, p.gate, 0.f, s);
         if (!BWD) {
             if (ok) {
 #pragma unroll
@@ -810,8 +978,36 @@ static void launch_pair_w(bool bwd, int nkw, dim3 grid, size_t lds, hipStream_t 
     if (nkw == 1) XLAUNCH(1); else if (nkw == 2) XLAUNCH(2); else if (nkw == 3) XLAUNCH(3); else XLAUNCH(4);
 #undef XLAUNCH
 }
+static int g_xstop = 0;
+extern "C" int dvlp_xattn_bwd_stop(int stage) { g_xstop = stage; return DVLP_OK; }
+static int g_xbwd_packed = 1;    // bf16 backward: 1 = xsoftmax_bwd_bf16_kernel, 0 = the generic kernel (A/B, tests)
+extern "C" int dvlp_xattn_bwd_variant(int packed) { g_xbwd_packed = packed; return DVLP_OK; }
+static size_t pair_lds_bf16_bwd(int64_t G, int64_t W) {
+    const int64_t Wq = W | 1;
+    return (size_t)(G * Wq + G + W + 8 * W + G + W + 16 * G + 32 * 32 * cdiv(rup(W, 8), 32)) * sizeof(float);
+}
+template <int NKG>
+static void launch_pair_bf16_bwd(int nkw, dim3 grid, size_t lds, hipStream_t st, const PairArgs& pa) {
+#define XLAUNCHB(NKW_) do { auto kb = xsoftmax_bwd_bf16_kernel<NKG, NKW_>; \
+        (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(kb, grid, dim3(XT), lds, st, pa); } while (0)
+    if (nkw == 1) XLAUNCHB(1); else if (nkw == 2) XLAUNCHB(2); else if (nkw == 3) XLAUNCHB(3); else XLAUNCHB(4);
+#undef XLAUNCHB
+}
 template <typename T>
 static void launch_pair(bool bwd, int nkg, int nkw, dim3 grid, size_t lds, hipStream_t st, const PairArgs& pa) {
+    if (bwd && sizeof(T) == 2 && g_xbwd_packed) {
+        const size_t ldsb = pair_lds_bf16_bwd(pa.G, pa.W);
+        switch (nkg) {
+            case 1: launch_pair_bf16_bwd<1>(nkw, grid, ldsb, st, pa); break;
+            case 2: launch_pair_bf16_bwd<2>(nkw, grid, ldsb, st, pa); break;
+            case 3: launch_pair_bf16_bwd<3>(nkw, grid, ldsb, st, pa); break;
+            case 4: launch_pair_bf16_bwd<4>(nkw, grid, ldsb, st, pa); break;
+            case 5: launch_pair_bf16_bwd<5>(nkw, grid, ldsb, st, pa); break;
+            default: launch_pair_bf16_bwd<6>(nkw, grid, ldsb, st, pa); break;
+        }
+        return;
+    }
     switch (nkg) {
         case 1: launch_pair_w<T, 1>(bwd, nkw, grid, lds, st, pa); break;
         case 2: launch_pair_w<T, 2>(bwd, nkw, grid, lds, st, pa); break;
@@ -922,7 +1118,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     PairArgs pa{};
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.dP1 = dP1; pa.dP2 = dP2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
-    pa.lam = lam; pa.gate = gate;
+    pa.lam = lam; pa.gate = gate; pa.stop = g_xstop;
     if (!general) {
         if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 1);

@@ -154,6 +154,12 @@ int dvlp_xattn_force_general(int on);
 /* 1 (default): bf16 pairs with F*R <= 288, W <= 112 run the fused per-pair kernels (everything between the embeddings and the
    score on chip); 0: always the multi-kernel path -- for A/B measurements and tests */
 int dvlp_xattn_fused_mode(int mode);
+/* bf16 backward of the per-pair softmax stage: 1 (default) keeps both intermediate tiles on chip (LDS low halves / registers),
+   0 runs the generic kernel that round-trips them through the workspace -- for A/B measurements and tests */
+int dvlp_xattn_bwd_variant(int packed);
+/* TIMING-ONLY ablation of the bf16 per-pair backward kernel: leave after stage 1 (S tile + norms), 2 (image->text pass), 3 (text->image
+   pass); 0 in production */
+int dvlp_xattn_bwd_stop(int stage);
 /* TIMING-ONLY ablation of the fused forward kernel (stop after phase n); 0 in production */
 int dvlp_xfused_ablate(int stop);
 int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd);

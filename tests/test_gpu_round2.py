@@ -491,6 +491,47 @@ def test_fused_local_loss_forward_vs_oracle(B, G, W, gate):
     assert np.abs(res[1] - res[0]).max() < 2e-3
 
 
+@pytest.mark.parametrize("B,G,W", [(2, 288, 99), (3, 240, 37), (3, 30, 99), (2, 288, 112), (3, 100, 7), (2, 16, 128)])
+@pytest.mark.parametrize("gate", [True, False])
+def test_local_loss_backward_bf16_on_chip_tiles_vs_generic_and_oracle(B, G, W, gate):
+    """bf16 backward of the per-pair softmax stage with both intermediate tiles on chip (xsoftmax_bwd_bf16_kernel) against the generic
+    kernel that round-trips them through the workspace (same math, one bf16 rounding fewer on the text->image tile) and against the
+    fp64 oracle's autograd gradient on the same bf16-rounded inputs (1e-1 of the largest gradient: tests/test_gpu_kernels.py's bf16
+    tolerance for this multi-kernel path)."""
+    rng = np.random.default_rng(B * 977 + G + W)
+    im = rng.standard_normal((B, G, 256), dtype=np.float32)
+    cap = rng.standard_normal((B, W, 256), dtype=np.float32)
+    n = min(G, W)
+    cap[:, :n, :64] += im[:, :n, :64] * 0.5
+    m_img = np.zeros((B, G), np.float32)
+    m_img[1, max(0, G - 5):] = -100.0
+    lens = rng.integers(2, min(30, W), B)
+    m_cap = np.full((B, W), -100.0, np.float32)
+    for b in range(B):
+        m_cap[b, : lens[b]] = 0.0
+    dsc = rng.standard_normal((B, B)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    C, Q = t(im).bfloat16(), t(cap).bfloat16()
+    Cr, Qr = C.double().cpu().requires_grad_(True), Q.double().cpu().requires_grad_(True)
+    sc = orc.xattn_scores_batched(Cr, Qr, torch.from_numpy(m_img).double(), torch.from_numpy(m_cap).double(), 20.0, gate)
+    (sc * torch.from_numpy(dsc).double()).sum().backward()
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.call("dvlp_xattn_bwd_variant", mode)
+            _, ws = ops.xattn_fwd(C, Q, t(m_img), t(m_cap), 20.0, gate, True)
+            dC, dQ = ops.xattn_bwd(C, Q, t(m_img), t(m_cap), 20.0, gate, t(dsc), ws)
+            res[mode] = (dC.float().cpu().numpy(), dQ.float().cpu().numpy())
+    finally:
+        ops.call("dvlp_xattn_bwd_variant", 1)
+    for k, ref in enumerate((Cr.grad.numpy(), Qr.grad.numpy())):
+        scale = np.abs(ref).max()
+        assert np.abs(res[1][k] - res[0][k]).max() <= 2e-2 * scale, (k, np.abs(res[1][k] - res[0][k]).max(), scale)
+        assert np.abs(res[1][k] - ref).max() <= 1e-1 * scale, (k, np.abs(res[1][k] - ref).max(), scale)
+        # the on-chip form is never further from the oracle than the generic one by more than rounding noise
+        assert np.abs(res[1][k] - ref).max() <= np.abs(res[0][k] - ref).max() + 1e-2 * scale
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_philox_on_device_and_dropout_masks_vs_oracle():
     """Device Philox4x32-10 against the published known-answer vectors; the element-wise dropout kernel and the attention keep
