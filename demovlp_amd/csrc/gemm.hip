@@ -1377,7 +1377,9 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         // (measured per shape with tools/gemm_sweep.py: 75-tile outputs with K = 2304 / 3072 -- the text tower's fc2, fc1 dX, qkv dX -- run
         //  faster on the 128-row kernel without a K split than on a 3-way split 256-row launch (47 vs 55, 38 vs 50, 48 vs 55 us), and a
         //  3-tile weight gradient -- the two 256-wide projections -- on 384 128-row blocks than on 96 256-row ones)
-        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= 192 && rounds8) || (tiles8 >= 8 && tiles8 <= 64 && K >= 4096))));
+        static const int p8_min_tiles = getenv("DVLP_P8_MIN_TILES") ? atoi(getenv("DVLP_P8_MIN_TILES")) : 192;      // experiments
+        static const bool p8_need_rounds = getenv("DVLP_P8_ROUNDS") ? atoi(getenv("DVLP_P8_ROUNDS")) != 0 : true;
+        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= p8_min_tiles && (rounds8 || !p8_need_rounds)) || (tiles8 >= 8 && tiles8 <= 64 && K >= 4096))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
         // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32
         // slabs (deterministic, no float atomics).

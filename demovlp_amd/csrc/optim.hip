@@ -95,3 +95,22 @@ extern "C" int dvlp_adamw_step_dev(int64_t n, float* p, const float* g, float* m
     hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (const float*)hyper, (bf16*)bf16_shadow);
     return dvlp_launch_status();
 }
+
+// The same update in two parts, for a step whose optimizer work is spread over the backward pass: dvlp_adamw_prep_dev advances the
+// device step counter / step size ONCE (before the first partial update of the step), dvlp_adamw_range_dev updates one range of the
+// flat buffers with the hyper-parameters as they stand (trainer.FusedAdamW.begin_overlapped: a layer's weights are updated on the
+// gradient side stream as soon as its weight gradients are final -- the HBM-bound update hides behind the MFMA-bound backward).
+extern "C" int dvlp_adamw_prep_dev(float* hyper, void* stream) {
+    dvlp_clear_status();
+    if (!hyper) return DVLP_ERR_SHAPE;
+    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
+    return dvlp_launch_status();
+}
+extern "C" int dvlp_adamw_range_dev(int64_t n, float* p, const float* g, float* m, float* v, const float* hyper, void* bf16_shadow, void* stream) {
+    dvlp_clear_status();
+    if (n <= 0 || !hyper) return DVLP_ERR_SHAPE;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)bf16_shadow & 7)) return DVLP_ERR_SHAPE;   // vector accesses
+    int64_t blocks = cdiv(n, 1024); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, hyper, (bf16*)bf16_shadow);
+    return dvlp_launch_status();
+}

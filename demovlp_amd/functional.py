@@ -116,6 +116,19 @@ def _wgrad_group(items):
         return ops.wgrad_grouped([(dy2d, x2d, _grad_buf(dst) if isinstance(dst, torch.nn.Parameter) else dst) for dy2d, x2d, dst in items])
 
 
+EARLY_OPT = None          # trainer.FusedAdamW.begin_overlapped installs its per-layer update here for the duration of one backward
+
+
+def _early_update(params):
+    """End of a layer's backward: its weight gradients are final (side stream) and its weights have been read for the last time this
+    step (current stream), so the optimizer may update them now -- on the side stream, behind both (``_Side`` waits for the current
+    stream).  The HBM-bound update then runs beside the MFMA-bound rest of the backward instead of after it."""
+    if EARLY_OPT is None:
+        return
+    with _Side(level=2):
+        EARLY_OPT(params)
+
+
 FUSE_TEXT_QKV = os.environ.get("DVLP_NO_FUSED_QKV") is None      # developer switch for A/B timing
 FUSE_LN_COLSUM = os.environ.get("DVLP_NO_LN_COLSUM") is None     # developer switch for A/B timing
 FUSE_GEMM_COLSUM = os.environ.get("DVLP_NO_GEMM_COLSUM") is None  # developer switch for A/B timing
@@ -311,6 +324,7 @@ class VitBlockFn(torch.autograd.Function):
         # the four weight gradients of the block (9-36 output tiles each, K = B*N tokens) as ONE grouped GEMM
         df2w, df1w, dpw, dqkvw = _wgrad_group([(dy2, a, f2w), (dpre, h2, f1w), (dx1, att, pw), (dqkv, h1, qkvw)])
         dx, dn1w, dn1b = _ln_bwd(dh1, x2, n1w, n1b, m1, r1, dres=dx1)
+        _early_update((qkvw, pw, f1w, f2w))
         return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None)
 
 
@@ -372,6 +386,7 @@ class TimeSpaceBlockFn(torch.autograd.Function):
         df2w, df1w, dpw, dqkvw, dtpw, dtqw = _wgrad_group([(dy2, a, f2w), (dpre, h2, f1w), (dx1, att, pw), (dqkv, h1, qkvw),
                                                            (dtout, tatt, tpw), (dtqkv, h3t, tqw)])
         dx, dn3w, dn3b = _ln_bwd(dh3, x2, n3w, n3b, m3, r3, dres=dres)
+        _early_update((tqw, tpw, qkvw, pw, f1w, f2w))
         return (dx.reshape(B, N, -1), None, None, dn3w, dn3b, dtqw, dtqb, dtpw, dtpb, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b,
                 df1w, df1b, df2w, df2b, None, None)
 
@@ -498,6 +513,7 @@ class BertLayerFn(torch.autograd.Function):
             dx = ops.linear_bwd_input(dq, SHADOWS.get(qw, cd), res=ds1)
             ops.linear_bwd_input(dk, SHADOWS.get(kw, cd), out=dx, accumulate=True)
             ops.linear_bwd_input(dv, SHADOWS.get(vw, cd), out=dx, accumulate=True)
+        _early_update((qw, kw, vw, ow, f1w, f2w))
         return (dx.reshape(B, L, -1), None, dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, dl1w, dl1b, df1w, df1b, df2w, df2b, dl2w, dl2b, None, None)
 
 

@@ -510,6 +510,17 @@ def adamw_step_dev(pflat, gflat, m, v, hyper, shadow=None):
     call("dvlp_adamw_step_dev", pflat.numel(), p(pflat), p(gflat), p(m), p(v), p(hyper), p(shadow), stream())
 
 
+def adamw_prep_dev(hyper):
+    """Advance the device step counter / step size once (first half of adamw_step_dev)."""
+    call("dvlp_adamw_prep_dev", p(hyper), stream())
+
+
+def adamw_range_dev(pflat, gflat, m, v, hyper, shadow, lo, hi):
+    """Second half of adamw_step_dev on elements [lo, hi) of the flat buffers (lo a multiple of 4)."""
+    call("dvlp_adamw_range_dev", hi - lo, p(pflat[lo:hi]), p(gflat[lo:hi]), p(m[lo:hi]), p(v[lo:hi]), p(hyper),
+         p(shadow[lo:hi]) if shadow is not None else None, stream())
+
+
 def prof_enable(on: bool):
     call("dvlp_prof_enable", int(on))
 

@@ -114,6 +114,8 @@ class FusedAdamW:
         self._ever = set()            # arena indices that have received a gradient at least once (own HF-style state)
         self._backwards = {}
         self._hyper, self._hyper_host, self._hyper_step = None, None, 0
+        self._early = None            # (lo, hi) ranges already updated in this step (begin_overlapped), else None
+        self._index_of = {id(p): i for i, p in enumerate(arena.params)}
         if arena.flat_p.is_cuda:
             ops.enable_deferred_reductions(arena.flat_p.device)
         # gradients are WRITTEN (not accumulated) into the arena by the backward kernels: a second backward() before step()
@@ -126,6 +128,8 @@ class FusedAdamW:
         for p in self.arena.params:
             p.grad = None
         self._backwards = {}
+        if self._early is not None:
+            raise RuntimeError("FusedAdamW: begin_overlapped() without a matching step() / launch()")
 
     def _adopt_stray_grads(self):
         """Every gradient must live in its arena slice for the flat update (and the bucketed all-reduce).  The kernels write
@@ -162,12 +166,56 @@ class FusedAdamW:
             self._hyper[6:7].fill_(float(self.step_count))
             self._hyper_step = self.step_count
 
+    # ---- update spread over the backward pass ---------------------------------------------------------------------
+    def begin_overlapped(self, grad_scale=1.0):
+        """Call after zero_grad() and before the step's forward / backward (no gradient exchange between ranks in this step): the
+        device step counter advances now, and every transformer layer's weights -- 71 % of the parameters -- are updated on the
+        gradient side stream at the end of that layer's backward (functional._early_update), where the HBM-bound update runs
+        beside the MFMA-bound backward; launch() then only covers what is left (embeddings, heads, the vector tail).  Element for
+        element the same arithmetic as the single launch."""
+        if not self.arena.flat_p.is_cuda:
+            return
+        self._sync_hyper(grad_scale)
+        ops.adamw_prep_dev(self._hyper)
+        self._early = []
+        Fn.EARLY_OPT = self._early_update
+
+    def _early_update(self, params):
+        a = self.arena
+        idx = sorted(self._index_of[id(q)] for q in params)
+        runs = []
+        for i in idx:                                           # adjacent slices (a layer's matrices are) merge into one launch
+            lo, hi = a.offsets[i], a.offsets[i] + (a.params[i].numel() + a.ALIGN - 1) // a.ALIGN * a.ALIGN
+            if runs and runs[-1][1] == lo:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi])
+        for lo, hi in runs:
+            ops.adamw_range_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s, lo, hi)
+            self._early.append((lo, hi))
+
+    def _finish_overlapped(self):
+        """The ranges no layer updated, as few launches as the arena layout allows."""
+        a = self.arena
+        Fn.EARLY_OPT = None
+        done, self._early = sorted(self._early), None
+        pos = 0
+        for lo, hi in done + [(a.total, a.total)]:
+            if lo > pos:
+                ops.adamw_range_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s, pos, lo)
+            pos = max(pos, hi)
+
     def launch(self, grad_scale=1.0):
         """Device-side part: the fused update (hyper-parameters and the step counter live in device memory, so this launch can sit
         inside a captured hipGraph and be replayed)."""
         a = self.arena
-        self._sync_hyper(grad_scale)
-        ops.adamw_step_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s)
+        if self._early is not None:
+            if float(grad_scale) != self._hyper_host[5]:
+                raise RuntimeError("FusedAdamW: grad_scale changed between begin_overlapped() and launch()")
+            self._finish_overlapped()
+        else:
+            self._sync_hyper(grad_scale)
+            ops.adamw_step_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s)
         self.step_count += 1
         self._hyper_step = self.step_count
         if a.flat_s is not None:
@@ -392,6 +440,8 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
     optimizer.zero_grad()
     if reducer is not None:
         reducer.begin()
+    elif isinstance(optimizer, FusedAdamW) and not (dist.is_initialized() and dist.get_world_size() > 1):
+        optimizer.begin_overlapped()           # no gradient exchange: the layers' updates ride along with the backward
     losses = forward_backward(model, loss_fn, data, gather_negatives)
     scale = reducer.finish() if reducer is not None else 1.0
     if isinstance(optimizer, FusedAdamW):
@@ -436,6 +486,8 @@ class GraphedTrainStep:
 
     def _eager(self, data):
         self.opt.zero_grad()
+        if not self.collective:
+            self.opt.begin_overlapped()
         losses = forward_backward(self.model, self.loss_fn, data)
         self.opt.prepare()
         if self.collective:
@@ -452,6 +504,8 @@ class GraphedTrainStep:
         self.opt._sync_hyper(1.0 / self.world)              # no host->device copy may happen inside the capture
         with torch.cuda.graph(self.graph):
             self.opt.zero_grad()
+            if not self.collective:
+                self.opt.begin_overlapped()
             self.out = forward_backward(self.model, self.loss_fn, self.static)
             self.opt.prepare()
             if not self.collective:

@@ -188,6 +188,11 @@ int dvlp_adamw_step(int64_t n, float* p, const float* g, float* m, float* v, flo
    step_size}; each call first advances hyper[6] (the step counter) and recomputes hyper[7] on the device, so one captured hipGraph of
    a training step replays with the right bias correction, and lr / grad_scale change by writing the buffer */
 int dvlp_adamw_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float* hyper, void* bf16_shadow, void* stream);
+/* the two halves of dvlp_adamw_step_dev, for a step whose update is spread over the backward pass: _prep advances the device step
+   counter / step size once per step, _range updates n elements at the given (16-byte aligned) pointers with the hyper-parameters as
+   they stand */
+int dvlp_adamw_prep_dev(float* hyper, void* stream);
+int dvlp_adamw_range_dev(int64_t n, float* p, const float* g, float* m, float* v, const float* hyper, void* bf16_shadow, void* stream);
 
 #ifdef __cplusplus
 }
