@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     }
     const bool whole = e.vec && n0 + 256 <= N && !slab_out;   // every 8-column group of this block is whole and 16-byte aligned
     if (whole) {
-        const int fl = EK == P8_EK_ANY ? e.flags : EK == 2 ? EPI_GELU : EK == 3 ? EPI_GELU_BWD : 0;
+        const int fl = EK == P8_EK_ANY ? e.flags : EK == 2 ? EPI_GELU : EK == 3 ? EPI_GELU_BWD : (e.flags & EPI_LEAKY);   // LeakyReLU: no loads, stays a run-time test
         const bool has_res = EK == P8_EK_ANY ? e.res != nullptr : EK == 1, has_aux = (fl & (EPI_GELU_BWD | EPI_RELU_BWD)) != 0;
         const int64_t cn0 = n0 + 32 * wc + 16 * (g4 & 1) + 8 * (g4 >> 1);      // + 128 hh: this lane's 8 columns after the swap
         float4 bb[2][2];
@@ -1427,7 +1427,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         dim3 gridw((unsigned)(ntm_w * ntn), (unsigned)batch, (unsigned)S);
         dim3 grid8((unsigned)(ntm8 * ntn8), (unsigned)batch, (unsigned)S);
         // epilogue kind of the 256-row kernel (see p8_tile)
-        const int fmask8 = flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD | EPI_ACCUM | EPI_OUT_F32 | EPI_LEAKY);
+        const int fmask8 = flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD | EPI_ACCUM | EPI_OUT_F32);
         const int ek8 = g_ablate ? P8_EK_ANY : fmask8 == 0 ? (res ? 1 : 0) : (fmask8 == EPI_GELU && !res) ? 2 : (fmask8 == EPI_GELU_BWD && !res) ? 3 : P8_EK_ANY;
 #define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         rec.kern = p8 ? 2 : dma ? 1 : 0;

@@ -1047,9 +1047,9 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
         hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const bf16*)Craw, (bf16*)chat);
         hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (bf16*)qhat);
     }
-    // S[i] [G x Bj*Wp] = LeakyReLU(Chat_i [G x d] . Qhat^T)
-    XG(dtype, 0, 0, G, Bj * Wp, XD, chat, XD, qhat, XD, S, Bj * Wp, nullptr, nullptr, 0, nullptr, 0, EPI_LEAKY, 1.f, Bi, G * XD, 0,
-       G * Bj * Wp, 0, 0, stream);
+    // S [Bi*G x Bj*Wp] = LeakyReLU(Chat [Bi*G x d] . Qhat^T): every pair at once is ONE plain product (Qhat is shared by all videos),
+    // which the 256-row kernel takes (1872 tiles); as Bi batches of G = 288 rows it ran on the 128-row kernel at half the rate
+    XG(dtype, 0, 0, Bi * G, Bj * Wp, XD, chat, XD, qhat, XD, S, Bj * Wp, nullptr, nullptr, 0, nullptr, 0, EPI_LEAKY, 1.f, 1, 0, 0, 0, 0, 0, stream);
     PairArgs pa{};
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
