@@ -94,7 +94,7 @@ if mc:
                               "mfma_mops_bf16_per_launch": round(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / max(cnt[f], 1))}
     json.dump(out, open(os.path.join(P, tag + "_mfma_lds_pmc.json"), "w"), indent=1)
     print(json.dumps(out["families"], indent=1))
-for extra in ("select_bench.txt", "xfused_check.txt"):
+for extra in ("select_bench.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt"):
     src = os.path.join(SRC, extra)
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]

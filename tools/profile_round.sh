@@ -16,6 +16,11 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_C
 # K1 alone and the local-loss kernels alone
 timeout 300 python3 $R/tools/select_bench.py > $O/select_bench.txt 2>&1
 timeout 300 python3 $R/tools/xfused_check.py > $O/xfused_check.txt 2>&1
+# the local loss forward / backward alone, the epilogue breakdown of the 256-row kernel, and the stock library on the hot shapes (yardstick)
+timeout 300 python3 $R/tools/xloss_bench.py > $O/xloss_bench.txt 2>&1
+timeout 300 python3 $R/tools/epi_bench.py > $O/epi_bench.txt 2>&1
+timeout 300 python3 $R/tools/lib_gemm_ref.py > $O/lib_gemm_ref.txt 2>&1
+DVLP_PROF_REPORT=1 timeout 300 python3 $R/bench.py --no-cpu-baseline --no-object-tower --steps 10 --warmup 3 2>&1 | grep "kern=" | sort > $O/gemm_shapes.txt
 # keep what travels back small: the per-dispatch traces are large
 for d in trace fetch write mfma; do find $O/$d -name "*kernel_trace.csv" -size +20M -delete; done
 ls -la $O $O/trace $O/fetch $O/write $O/mfma
