@@ -327,6 +327,11 @@ def main():
             out["per_rank_pairs_per_s"] = per_rank
             out["grad_allreduce_ms_standalone"] = allreduce_ms
             out["grad_allreduce_bytes"] = int(arena.flat_g.numel() * 4)
+            if use_graph and getattr(stepper, "graph2", None) is not None:
+                early = sum(hi - lo for lo, hi in stepper.early_runs) * 4
+                out["grad_exchange"] = ("backward captured as two graphs cut at object block %d: %d MB (text tower + upper object blocks) all-reduced on a "
+                                        "communication stream while the second graph runs, %d MB behind it" % (stepper.cut, early >> 20, (arena.flat_g.numel() * 4 - early) >> 20))
+                out["launch_mode"] = out["launch_mode"].replace("1 graph per step", "2 graphs per step")
         if gemm_n:
             # HBM-side traffic per launch of the GEMM family cannot be self-measured from inside the process: it comes from
             # the committed rocprofv3 PMC passes of this same command, regenerated every round (tools/profile_round.sh)

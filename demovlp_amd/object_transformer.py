@@ -96,6 +96,8 @@ class ObjectTransformer(nn.Module):
         nn.init.trunc_normal_(self.custom_pos_embed, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.compute_dtype = torch.float32
+        self.grad_cut = None           # block index at which backward is cut in two (data-parallel graph step), None = one piece
+        self._cut = None
 
     def forward_features(self, x, x_mask):
         B, F, R, C = x.shape
@@ -112,9 +114,20 @@ class ObjectTransformer(nn.Module):
         if self.time_module == "timeattn":
             from . import ops
             addmask_t = ops.token_transpose(addmask.reshape(B, 1 + F * R, 1), B, F, R).reshape(B, 1 + F * R)     # key mask in region-major order
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
+            if self.grad_cut is not None and i == self.grad_cut and tok.requires_grad and torch.is_grad_enabled():
+                # backward in two pieces (trainer.backward_first / backward_second): autograd stops at this leaf, the caller exchanges
+                # the gradients that are final by then, and resumes from the leaf's gradient
+                leaf = tok.detach().requires_grad_(True)
+                self._cut = (tok, leaf)
+                tok = leaf
             tok = blk(tok, addmask, F, R, addmask_t)
         return tok, addmask
+
+    def take_cut(self):
+        """(tokens entering block ``grad_cut``, the leaf that replaced them) of the last forward, or None; clears it."""
+        cut, self._cut = self._cut, None
+        return cut
 
     def forward(self, x, x_mask):
         """x [B,F,R,2054], x_mask [B,F,R] (1 = real region) -> (embeddings [B,N,256], additive mask [B,N])."""

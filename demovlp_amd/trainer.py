@@ -414,9 +414,10 @@ def gather_embeddings(out, text_length, text_mask, args):
     return gathered, _gather_plain(text_length, n_gpu), _gather_plain(text_mask, n_gpu)
 
 
-def forward_backward(model, loss_fn, data, gather_negatives=None):
-    """trainer/trainer_dist.py:148-165: forward, masks, sim_matrix, GlobalLocalLoss, backward (+ the batched final reduction of the
-    bias / LayerNorm gradients).  Returns the three detached losses."""
+def backward_first(model, loss_fn, data, gather_negatives=None):
+    """trainer/trainer_dist.py:148-165: forward, masks, sim_matrix, GlobalLocalLoss and ``loss.backward()``.  When the object tower
+    carries a ``grad_cut`` the backward stops at that block's input (text tower, heads and the upper object blocks are done; their
+    gradients are final when this returns) and ``backward_second`` finishes it.  Returns the three detached losses."""
     text_length = torch.sum(data["text"]["attention_mask"], dim=1)
     out = model(data)
     text_mask = data["text"]["attention_mask"][:, 1:].contiguous()
@@ -428,9 +429,27 @@ def forward_backward(model, loss_fn, data, gather_negatives=None):
                                             out["object_mask"], text_length, text_mask)
     loss.backward()
     if loss.is_cuda:
+        Fn.join_side_stream()          # weight gradients (side stream) and the text tower's stream
+    return loss.detach(), global_loss.detach(), local_loss.detach()
+
+
+def backward_second(model):
+    """The rest of a cut backward (no-op without a cut) + the batched final reduction of the bias / LayerNorm gradients."""
+    om = getattr(model, "object_model", None)
+    cut = om.take_cut() if om is not None and hasattr(om, "take_cut") else None
+    if cut is not None:
+        tok, leaf = cut
+        torch.autograd.backward(tok, leaf.grad)
+    if torch.cuda.is_available() and next(model.parameters()).is_cuda:
         Fn.join_side_stream()          # deferred partial sums may have been produced on the side stream
         ops.flush_reductions()
-    return loss.detach(), global_loss.detach(), local_loss.detach()
+
+
+def forward_backward(model, loss_fn, data, gather_negatives=None):
+    """One forward + backward (both pieces when the object tower carries a ``grad_cut``).  Returns the three detached losses."""
+    losses = backward_first(model, loss_fn, data, gather_negatives)
+    backward_second(model)
+    return losses
 
 
 def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = None, gather_negatives=None):
@@ -461,11 +480,14 @@ class GraphedTrainStep:
     final reduction, fused AdamW: ~520 launches -- and every later call copies the batch into the captured input buffers and
     replays.  The host's per-launch Python / ctypes / autograd cost (~40 us x 520) disappears from the step.
 
-    Data parallel (``world > 1``): the gradient all-reduce is NOT captured (no collective inside a graph): the graph ends after
-    backward, the arena's gradients are all-reduced in bucket-sized pieces on the same stream, and the optimizer launch follows
-    eagerly.  Static shapes only: a batch of another shape re-captures."""
+    Data parallel (``world > 1``): no collective is captured.  The backward is cut in two at object block ``cut`` and captured as TWO
+    graphs: when the first has run, the text tower's and the upper object blocks' weight gradients (~70 % of the bytes, contiguous
+    arena ranges) are final and their all-reduce is issued on a communication stream while the second graph -- the lower object
+    blocks -- runs; only the rest (lower blocks, embeddings, the vector tail) is exchanged behind the second graph, and the optimizer
+    launch follows eagerly.  Static shapes only: a batch of another shape re-captures."""
 
-    def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 256.0, always_reduce: bool = False):
+    def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 256.0, always_reduce: bool = False,
+                 cut: int | None = 6):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.warmup, self.calls = max(1, warmup), 0
         self.group = group
@@ -473,25 +495,84 @@ class GraphedTrainStep:
         self.bucket = int(bucket_mb * 1024 * 1024 / 4)
         # always_reduce: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
         self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
-        self.graph, self.static, self.out, self.shape_key = None, None, None, None
+        self.graph, self.graph2, self.static, self.out, self.shape_key = None, None, None, None, None
+        self.cut, self.early_runs, self.late_runs, self._comm = None, [], [(0, optimizer.arena.total)], None
+        om = getattr(model, "object_model", None)
+        if self.collective and cut and om is not None and hasattr(om, "grad_cut") and 0 < cut < len(om.blocks):
+            self.cut = int(cut)
+            self.early_runs, self.late_runs = self.plan_exchange(optimizer.arena, self.cut)
+
+    @staticmethod
+    def plan_exchange(arena, cut):
+        """Arena ranges whose gradients are final after the first piece of a backward cut at object block ``cut`` (the text tower's
+        matrices and object blocks >= cut: two contiguous runs in the arena's matrices-first order), and the complement."""
+        def early(n):
+            return n.startswith("text_model.") or (n.startswith("object_model.blocks.") and int(n.split(".")[2]) >= cut)
+        runs = []
+        for i in range(arena.n_matrix):
+            if early(arena.names[i]):
+                lo = arena.offsets[i]
+                hi = lo + (arena.params[i].numel() + arena.ALIGN - 1) // arena.ALIGN * arena.ALIGN
+                if runs and runs[-1][1] == lo:
+                    runs[-1][1] = hi
+                else:
+                    runs.append([lo, hi])
+        runs = [(lo, hi) for lo, hi in runs if hi - lo >= (1 << 18)]          # tiny runs are not worth a collective of their own
+        late, pos = [], 0
+        for lo, hi in runs + [(arena.total, arena.total)]:
+            if lo > pos:
+                late.append((pos, lo))
+            pos = hi
+        return runs, late
 
     @staticmethod
     def _key(data):
         return tuple((tuple(t.shape), t.dtype) for t in (data["text"]["input_ids"], data["text"]["attention_mask"], data["object"], data["object_mask"]))
 
-    def _allreduce(self):
+    def _pieces(self, runs):
+        for lo, hi in runs:
+            for p in range(lo, hi, self.bucket):
+                yield p, min(hi, p + self.bucket)
+
+    def _exchange(self, runs, overlapped=False):
+        """Sum the given arena ranges of the gradient buffer over the ranks; ``overlapped``: on the communication stream, behind
+        what the current stream holds so far -- returns the handles to wait on."""
         g = self.opt.arena.flat_g
-        for lo in range(0, g.numel(), self.bucket):
-            dist.all_reduce(g[lo:lo + self.bucket], op=dist.ReduceOp.SUM, group=self.group)
+        if not overlapped or not g.is_cuda:
+            for lo, hi in self._pieces(runs):
+                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            return []
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=g.device)
+        self._comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            return [dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in self._pieces(runs)]
+
+    def _allreduce(self):
+        self._exchange([(0, self.opt.arena.total)])
+
+    def _set_cut(self, on=True):
+        # only for this object's own forward: a caller that runs ``loss.backward()`` itself must get the whole backward
+        if self.cut is not None:
+            self.model.object_model.grad_cut = self.cut if on else None
 
     def _eager(self, data):
         self.opt.zero_grad()
         if not self.collective:
             self.opt.begin_overlapped()
-        losses = forward_backward(self.model, self.loss_fn, data)
+        self._set_cut()
+        losses = backward_first(self.model, self.loss_fn, data)
+        self._set_cut(False)
+        handles = []
+        if self.cut is not None:
+            self.opt._adopt_stray_grads()
+            handles = self._exchange(self.early_runs, overlapped=True)
+        backward_second(self.model)
         self.opt.prepare()
         if self.collective:
-            self._allreduce()
+            self._exchange(self.late_runs)
+            for h in handles:
+                h.wait()
         self.opt.launch(grad_scale=1.0 / self.world)
         return losses
 
@@ -500,18 +581,31 @@ class GraphedTrainStep:
                        "object_mask": data["object_mask"].clone()}
         self.shape_key = self._key(data)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph, self.graph2 = torch.cuda.CUDAGraph(), None
         self.opt._sync_hyper(1.0 / self.world)              # no host->device copy may happen inside the capture
+        self._set_cut()
+        if self.cut is None:
+            with torch.cuda.graph(self.graph):
+                self.opt.zero_grad()
+                if not self.collective:
+                    self.opt.begin_overlapped()
+                self.out = forward_backward(self.model, self.loss_fn, self.static)
+                self.opt.prepare()
+                if not self.collective:
+                    self.opt.launch(grad_scale=1.0)
+            if not self.collective:
+                self.opt.step_count -= 1                      # launch() counted a step, but capturing executed nothing
+            return
+        # two graphs sharing one memory pool: the second consumes what the first saved (activations, the cut's gradient)
         with torch.cuda.graph(self.graph):
             self.opt.zero_grad()
-            if not self.collective:
-                self.opt.begin_overlapped()
-            self.out = forward_backward(self.model, self.loss_fn, self.static)
+            self.out = backward_first(self.model, self.loss_fn, self.static)
+            self.opt._adopt_stray_grads()
+        self._set_cut(False)
+        self.graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+            backward_second(self.model)
             self.opt.prepare()
-            if not self.collective:
-                self.opt.launch(grad_scale=1.0)
-        if not self.collective:
-            self.opt.step_count -= 1                          # launch() counted a step, but capturing executed nothing
 
     def __call__(self, data):
         self.calls += 1
@@ -527,9 +621,15 @@ class GraphedTrainStep:
         self.graph.replay()
         if not self.collective:
             self.opt.replayed()
-        else:
-            self._allreduce()
-            self.opt.launch(grad_scale=1.0 / self.world)
+            return self.out
+        handles = []
+        if self.graph2 is not None:
+            handles = self._exchange(self.early_runs, overlapped=True)     # travels while the second graph runs
+            self.graph2.replay()
+        self._exchange(self.late_runs)
+        for h in handles:
+            h.wait()
+        self.opt.launch(grad_scale=1.0 / self.world)
         return self.out
 
 

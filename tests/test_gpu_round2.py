@@ -384,6 +384,45 @@ def test_bench_rccl_path_in_a_one_rank_group(graph):
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
     assert out["roofline"]["object_transformer_frac"] > 0
     assert np.isfinite(out["config"]["final_loss"])
+    # the two exchange schemes (and the plain single-GPU step) train the same model: compare against a run without a process group
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DVLP_FORCE_DIST")}
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
+                         "--no-cpu-baseline", "--no-object-tower", "--no-kernel-timing", "--graph", str(graph)], env=env1, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    ref = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(out["config"]["final_loss"] - ref["config"]["final_loss"]) < 2e-3 * abs(ref["config"]["final_loss"]), (out["config"], ref["config"])
+
+
+def test_backward_cut_in_two_gives_the_same_gradients():
+    """The data-parallel graph step cuts the backward at an object block (trainer.backward_first / backward_second) so that the first
+    piece's gradients can travel while the second runs: same kernels in the same order, so every gradient is bit-identical to the
+    one-piece backward (F=2, R=8, B=3; cut at block 5)."""
+    from demovlp_amd.trainer import backward_first, backward_second
+    F, R, B = 2, 8, 3
+    model = build(F, R)
+    arena = ParamArena(model)
+    data = to_dev(*golden_batch(F, R, B))
+    lf = loss_head()
+    FusedAdamW(arena, lr=1e-5)             # enables the deferred reductions, as in training
+    grads = []
+    for cut in (None, 5):
+        for p in arena.params:
+            p.grad = None
+        arena.flat_g.zero_()
+        model.object_model.grad_cut = cut
+        l = backward_first(model, lf, data)
+        if cut is not None:
+            assert model.object_model._cut is not None
+        backward_second(model)
+        torch.cuda.synchronize()
+        grads.append((l[0].item(), arena.flat_g.clone()))
+    model.object_model.grad_cut = None
+    assert grads[0][0] == grads[1][0]
+    assert grads[0][1].abs().max().item() > 0
+    # (the word-embedding gradient is a scatter-add with float atomics: it differs by an ulp between ANY two runs)
+    lo, hi = arena.slice_of(arena.names.index("text_model.embeddings.word_embeddings.weight"))
+    assert torch.equal(grads[0][1][hi:], grads[1][1][hi:]) and torch.equal(grads[0][1][:lo], grads[1][1][:lo])
+    assert (grads[0][1][lo:hi] - grads[1][1][lo:hi]).abs().max().item() < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -295,3 +295,31 @@ def test_fused_adamw_state_dict_uses_the_reference_checkpoint_layout():
     opt2.load_state_dict(sd)
     assert opt2.step_count == 5 and opt2.param_groups[0]["lr"] == 3e-4 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
     assert opt2._ever == opt._ever
+
+
+def test_two_graph_exchange_plan_covers_the_arena_once():
+    """GraphedTrainStep.plan_exchange: the ranges exchanged behind the first piece of a cut backward (text tower + object blocks >= cut)
+    and the ranges exchanged at the end are disjoint, ordered, and together cover the arena exactly; the early ones hold only tensors
+    whose gradients the first piece finishes."""
+    from types import SimpleNamespace
+    from demovlp_amd.trainer import GraphedTrainStep
+    names = (["text_model.embeddings.word_embeddings.weight"] + [f"text_model.transformer.layer.{l}.{w}.weight" for l in range(2) for w in ("q_lin", "ffn")]
+             + ["object_model.cls_token", "object_model.temporal_embed"] + [f"object_model.blocks.{b}.{w}.weight" for b in range(4) for w in ("attn.qkv", "mlp.fc1")]
+             + ["object_model.object_embedding.weight", "object_model.proj.weight", "txt_proj.1.weight"])
+    n_matrix = len(names)
+    names += ["text_model.some.bias", "object_model.blocks.0.norm1.weight"]
+    sizes = [300000 + 64 * i for i in range(len(names))]
+    offs, o = [], 0
+    for z in sizes:
+        offs.append(o)
+        o += (z + 63) // 64 * 64
+    arena = SimpleNamespace(names=names, offsets=offs, total=o, n_matrix=n_matrix, ALIGN=64, params=[SimpleNamespace(numel=lambda z=z: z) for z in sizes])
+    early, late = GraphedTrainStep.plan_exchange(arena, cut=2)
+    assert len(early) == 2                                       # the text tower, and object blocks 2..3
+    spans = sorted(list(early) + list(late))
+    assert spans[0][0] == 0 and spans[-1][1] == arena.total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for lo, hi in early:
+        inside = [n for n, off in zip(names, offs) if lo <= off < hi]
+        assert inside and all(n.startswith("text_model.") or int(n.split(".")[2]) >= 2 for n in inside)
+        assert all(names.index(n) < n_matrix for n in inside)
