@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
 // splitting K 7-28 ways, which costs ~65 MB of fp32 slabs per product.  Together they are ~110 tiles, so a 2-3 way split
 // fills the chip and the slab traffic drops ~4x.  Block ranges of the problems start at multiples of 8 so that the
 // XCD-aware tile order stays valid inside each problem.
-constexpr int P8G_MAX = 8;
+constexpr int P8G_MAX = 8, P8G_MAXP = 64;
 struct P8Group {
     int count;
     int blk0[P8G_MAX + 1];                 // first block of each problem (multiples of 8), blk0[count] = grid size
@@ -1157,19 +1157,34 @@ struct P8Group {
     const bf16* B[P8G_MAX];
     float* C[P8G_MAX];                     // final fp32 destination (S == 1: written directly)
     float* slab[P8G_MAX];                  // S > 1: [S][M][N] partials
+    // XCD patches (npatch > 0): patch i = up to 3 x 3 adjacent tiles of ONE K slice of one problem, run by the 9 blocks
+    // {8 (9 (i / 8) + w) + i % 8 : w < 9} -- all on XCD i % 8 (blocks are dealt to XCDs round-robin), all resident at once, all walking
+    // the same K range: the patch's 3 + 3 operand panels are fetched into that XCD's L2 once and shared, instead of each block
+    // streaming its own two (measured with FETCH_SIZE: 1.15 GB -> see profiles per ViT layer; 455 MB are unique)
+    int npatch;
+    unsigned char pp[P8G_MAXP], pz[P8G_MAXP], ptm[P8G_MAXP], ptn[P8G_MAXP], ppm[P8G_MAXP], ppn[P8G_MAXP];
 };
 __global__ __launch_bounds__(512) void gemm_bf16_p8_group_kernel(P8Group g, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < P8G_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.blk0[i]) p = i;
-    const int local = (int)blockIdx.x - g.blk0[p];
-    const int nblk = g.tiles[p] * g.S[p];
-    if (local >= nblk) return;                                  // padding block
-    const int64_t wg = xcd_remap(local, nblk);                  // blk0 is a multiple of 8, so local % 8 still names the XCD
-    const int z = (int)(wg / g.tiles[p]);
+    int p = 0, z;
     int64_t tm_, tn_;
-    tile_of(wg % g.tiles[p], g.tiles[p] / g.ntn[p], g.ntn[p], tm_, tn_);
+    if (g.npatch > 0) {
+        const int slot = (int)blockIdx.x >> 3, pi = ((int)blockIdx.x & 7) + 8 * (slot / 9), w = slot % 9;
+        if (pi >= g.npatch) return;
+        const int pm = g.ppm[pi], pn = g.ppn[pi];
+        if (w >= pm * pn) return;                                   // padding block of a partial patch
+        p = g.pp[pi]; z = g.pz[pi];
+        tm_ = g.ptm[pi] + w % pm; tn_ = g.ptn[pi] + w / pm;
+    } else {
+#pragma unroll
+        for (int i = 1; i < P8G_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.blk0[i]) p = i;
+        const int local = (int)blockIdx.x - g.blk0[p];
+        const int nblk = g.tiles[p] * g.S[p];
+        if (local >= nblk) return;                                  // padding block
+        const int64_t wg = xcd_remap(local, nblk);                  // blk0 is a multiple of 8, so local % 8 still names the XCD
+        z = (int)(wg / g.tiles[p]);
+        tile_of(wg % g.tiles[p], g.tiles[p] / g.ntn[p], g.ntn[p], tm_, tn_);
+    }
     const int64_t kbeg = z * g.kchunk[p], kend = kbeg + g.kchunk[p] < g.K[p] ? kbeg + g.kchunk[p] : g.K[p];
     Epi e{nullptr, nullptr, nullptr, 0, 0, flags | EPI_OUT_F32, 1.0f, 0, 0, 0, 0, 0, 1, nullptr};
     e.vec = (g.N[p] % 4 == 0) ? 1 : 0;
@@ -1235,6 +1250,8 @@ extern "C" int dvlp_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
 static bool g_use_glds = true;
 static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: measured no faster on this path's shapes), 1: heuristic, 2: always
 extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
+static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile patches pinned to XCDs (operand panels shared through L2), 0 = per-problem tile order
+extern "C" int dvlp_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
 extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
 static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
@@ -1536,6 +1553,29 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
     }
     g.blk0[count] = blk;
     r.count = nred; r.blk0[nred] = rblk;
+    // XCD patches (see P8Group): largest first, dealt round-robin, so every XCD gets the same number of blocks where the shapes allow
+    g.npatch = 0;
+    if (g_wgrad_patch) {
+        struct Pt { int p, z, tm, tn, pm, pn; };
+        std::vector<Pt> pts;
+        bool fits = true;
+        for (int p = 0; p < count && fits; ++p) {
+            const int ntm = (int)cdiv(M[p], 256), ntn = (int)cdiv(N[p], 256);
+            fits = ntm < 256 && ntn < 256 && S[p] < 256;
+            for (int z = 0; z < (int)S[p]; ++z)
+                for (int tm = 0; tm < ntm; tm += 3)
+                    for (int tn = 0; tn < ntn; tn += 3) pts.push_back(Pt{p, z, tm, tn, ntm - tm < 3 ? ntm - tm : 3, ntn - tn < 3 ? ntn - tn : 3});
+        }
+        if (fits && (int)pts.size() <= P8G_MAXP) {
+            std::stable_sort(pts.begin(), pts.end(), [](const Pt& a, const Pt& b) { return a.pm * a.pn > b.pm * b.pn; });
+            g.npatch = (int)pts.size();
+            for (int i = 0; i < g.npatch; ++i) {
+                g.pp[i] = (unsigned char)pts[i].p; g.pz[i] = (unsigned char)pts[i].z; g.ptm[i] = (unsigned char)pts[i].tm; g.ptn[i] = (unsigned char)pts[i].tn;
+                g.ppm[i] = (unsigned char)pts[i].pm; g.ppn[i] = (unsigned char)pts[i].pn;
+            }
+            blk = 72 * (int)cdiv(g.npatch, 8);
+        }
+    }
     ProfRec rec{};
     if (g_prof) {
         (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b);

@@ -94,6 +94,28 @@ if mc:
                               "mfma_mops_bf16_per_launch": round(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / max(cnt[f], 1))}
     json.dump(out, open(os.path.join(P, tag + "_mfma_lds_pmc.json"), "w"), indent=1)
     print(json.dumps(out["families"], indent=1))
+# L2<->fabric traffic per kernel (same two PMC passes): which launches re-read their operands
+if fc and wc:
+    import re
+
+    def by_kernel(path, counter):
+        agg, cnt = collections.defaultdict(float), collections.Counter()
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                k = re.sub(r"\(.*", "", r["Kernel_Name"])[:90]
+                agg[k] += float(r["Counter_Value"])
+                cnt[k] += 1
+        return agg, cnt
+    fa, fn_ = by_kernel(fc, "FETCH_SIZE")
+    wa, _ = by_kernel(wc, "WRITE_SIZE")
+    rows = sorted(((2.0 * fa[k] + wa.get(k, 0.0)) * 1024.0, k) for k in fa)[::-1]
+    total = sum(t for t, _ in rows)
+    table = [{"kernel": k, "launches": fn_[k], "read_mb_per_launch": round(2.0 * fa[k] * 1024 / fn_[k] / 1e6, 1),
+              "write_mb_per_launch": round(wa.get(k, 0.0) * 1024 / fn_[k] / 1e6, 1), "share_of_all_traffic": round(t / total, 4)} for t, k in rows[:25]]
+    json.dump({"source": "the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh (KiB counters; reads doubled per MI355X_MICROARCH.md); L2<->fabric, "
+                         "Infinity-Cache hits included, so HBM traffic proper is lower for operands that stay in the 256 MB MALL",
+               "kernels": table}, open(os.path.join(P, tag + "_traffic_by_kernel.json"), "w"), indent=1)
+
 for extra in ("select_bench.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt"):
     src = os.path.join(SRC, extra)
     if os.path.exists(src):
