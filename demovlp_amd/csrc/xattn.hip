@@ -16,6 +16,7 @@
 //   st1  [Bi][Bj][Wp][2]   st2 [Bj][Bi][G][2]     (dot, |wc|) per row, fp32
 //   dP1, dP2                                      backward only, same shapes as P1, P2 (then reused for D1, D2)
 #include "common.h"
+#include <cstdlib>
 
 constexpr int XD = 256;   // projection_dim (model/model.py:65)
 
@@ -1019,6 +1020,39 @@ static void launch_pair(bool bwd, int nkg, int nkw, dim3 grid, size_t lds, hipSt
 }
 #define XG(...) do { int rc_ = dvlp_gemm_batched(__VA_ARGS__); if (rc_) return rc_; } while (0)
 
+// The two directions of the loss (image->text / text->image) are independent between the softmax stages, and their contractions and
+// cosine passes are HBM-streaming kernels that reach 2.3-3.2 TB/s alone: the text->image half is issued on an internal side stream
+// beside the image->text half (fork / join by events -- legal inside a hipGraph capture), so the pair fills the memory system.
+// OFF by default (dvlp_xattn_parallel_halves(1) / DVLP_XATTN_PARALLEL=1 switch it on).
+static int g_xpar = getenv("DVLP_XATTN_PARALLEL") ? 1 : 0;     // opt-in: -0.2 ms on the B = 64 backward alone, within noise in the step
+extern "C" int dvlp_xattn_parallel_halves(int on) { g_xpar = on; return DVLP_OK; }
+struct XFork {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok() {
+        if (!g_xpar) return false;
+        if (!side) {
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+            (void)hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&join, hipEventDisableTiming);
+        }
+        return true;
+    }
+    // returns the stream the second half should use (the caller's own stream when forking is off)
+    hipStream_t begin(hipStream_t st) {
+        if (!ok()) return st;
+        (void)hipEventRecord(fork, st);
+        (void)hipStreamWaitEvent(side, fork, 0);
+        return side;
+    }
+    void end(hipStream_t st, hipStream_t second) {
+        if (second == st) return;
+        (void)hipEventRecord(join, second);
+        (void)hipStreamWaitEvent(st, join, 0);
+    }
+};
+static thread_local XFork t_xfork;
+
 extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                               const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd,
                               void* stream) {
@@ -1074,11 +1108,13 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
             hipLaunchKernelGGL((xg_t2i_kernel<bf16, false>), dim3((unsigned)ga.GC, (unsigned)Bj, (unsigned)Bi), b256, 0, st, ga); }
     }
     // wc[i] [(Bj*Wp) x d] = P1[i] [(Bj*Wp) x G] . Chat_i [G x d]
+    hipStream_t s2 = t_xfork.begin(st);
     XG(dtype, 0, 1, Bj * Wp, XD, G, P1, Gp, chat, XD, wc, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, G * XD,
        Bj * Wp * XD, 0, 0, stream);
     // wc2[j] [(Bi*G) x d] = P2[j] [(Bi*G) x Wp] . Qhat_j [Wp x d]
     XG(dtype, 0, 1, Bi * G, XD, Wp, P2, Wp, qhat, XD, wc2, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Wp * XD,
-       Bi * G * XD, 0, 0, stream);
+       Bi * G * XD, 0, 0, (void*)s2);
+    t_xfork.end(st, s2);
     CosArgs ca{};
     ca.Craw = Craw; ca.Qraw = Qraw; ca.wc = wc; ca.wc2 = wc2; ca.st1 = (float*)(ws + L.off_st1); ca.st2 = (float*)(ws + L.off_st2);
     ca.scores = scores; ca.Bi = (int)Bi; ca.Bj = (int)Bj; ca.G = (int)G; ca.W = (int)W; ca.Wp = (int)Wp;
@@ -1107,14 +1143,16 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     CosArgs ca{};
     ca.Craw = Craw; ca.Qraw = Qraw; ca.wc = wc; ca.wc2 = wc2; ca.st1 = (float*)(ws + L.off_st1); ca.st2 = (float*)(ws + L.off_st2);
     ca.dscores = dscores; ca.dirc = dirc; ca.dirq = dirq; ca.Bi = (int)Bi; ca.Bj = (int)Bj; ca.G = (int)G; ca.W = (int)W; ca.Wp = (int)Wp;
+    hipStream_t s2 = t_xfork.begin(st);
     DT(xcos_bwd_q_kernel, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, ca);       // wc  <- d wc
-    DT(xcos_bwd_c_kernel, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, ca);        // wc2 <- d wc2
+    DT(xcos_bwd_c_kernel, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, s2, ca);        // wc2 <- d wc2
     // dP1[i] [(Bj*Wp) x G] = dwc[i] [(Bj*Wp) x d] . Chat_i^T
     XG(dtype, 0, 0, Bj * Wp, G, XD, wc, XD, chat, XD, dP1, Gp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * XD, G * XD,
        Bj * Wp * Gp, 0, 0, stream);
     // dP2[j] [(Bi*G) x Wp] = dwc2[j] [(Bi*G) x d] . Qhat_j^T
     XG(dtype, 0, 0, Bi * G, Wp, XD, wc2, XD, qhat, XD, dP2, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * XD, Wp * XD,
-       Bi * G * Wp, 0, 0, stream);
+       Bi * G * Wp, 0, 0, (void*)s2);
+    t_xfork.end(st, s2);
     PairArgs pa{};
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.dP1 = dP1; pa.dP2 = dP2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
@@ -1142,15 +1180,17 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
             hipLaunchKernelGGL(xg_final_kernel<bf16>, gB, b256, lds3, st, ga); }
     }
     // dChat_i [G x d] = P1[i]^T [G x Bj*Wp] . dwc[i] [Bj*Wp x d]  +  dSraw[i] [G x Bj*Wp] . Qhat [Bj*Wp x d]
+    s2 = t_xfork.begin(st);
     XG(dtype, 1, 1, G, XD, Bj * Wp, P1, Gp, wc, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, Bj * Wp * XD,
        G * XD, 0, 0, stream);
     XG(dtype, 0, 1, G, XD, Bj * Wp, S, Bj * Wp, qhat, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bi, G * Bj * Wp, 0,
        G * XD, 0, 0, stream);
     // dQhat_j [Wp x d] = P2[j]^T [Wp x Bi*G] . dwc2[j] [Bi*G x d]  +  dSraw[:, :, j, :]^T [Wp x Bi*G] . Chat [Bi*G x d]
     XG(dtype, 1, 1, Wp, XD, Bi * G, P2, Wp, wc2, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Bi * G * XD,
-       Wp * XD, 0, 0, stream);
+       Wp * XD, 0, 0, (void*)s2);
     XG(dtype, 1, 1, Wp, XD, Bi * G, S, Bj * Wp, chat, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bj, Wp, 0, Wp * XD, 0,
-       0, stream);
+       0, (void*)s2);
+    t_xfork.end(st, s2);
     if (dtype == DVLP_F32) {
         hipLaunchKernelGGL(xprep_bwd_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (const float*)dchat, dirc, (float*)dC);
         hipLaunchKernelGGL(xprep_bwd_kernel<float>, dim3((unsigned)cdiv(Bj * W, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (const float*)dqhat, dirq, (float*)dQ);

@@ -160,6 +160,9 @@ int dvlp_xattn_fused_mode(int mode);
 /* bf16 backward of the per-pair softmax stage: 1 (default) keeps both intermediate tiles on chip (LDS low halves / registers),
    0 runs the generic kernel that round-trips them through the workspace -- for A/B measurements and tests */
 int dvlp_xattn_bwd_variant(int packed);
+/* 1: the text->image half of the local loss (its contractions and cosine passes) is issued on an internal side stream beside the
+   image->text half between the softmax stages (fork / join by events, capturable); 0 (default): everything on the caller's stream */
+int dvlp_xattn_parallel_halves(int on);
 /* TIMING-ONLY ablation of the bf16 per-pair backward kernel: leave after stage 1 (S tile + norms), 2 (image->text pass), 3 (text->image
    pass); 0 in production */
 int dvlp_xattn_bwd_stop(int stage);
