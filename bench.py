@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--overlap-wgrad", type=int, default=0,
                     help="side-stream gradient work: 0 off (default: per-kernel timings stay well defined), 1 bias-gradient reductions, "
                          "2 also weight-gradient GEMMs (+6%% pairs/s, but concurrent GEMMs stretch each other)")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
+                    help="developer A/B switch: call the C-ABI setter NAME (e.g. dvlp_xattn_gram=0) before the first step; repeatable")
     ap.add_argument("--p8", type=int, default=-1, help="override dvlp_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
     ap.add_argument("--no-object-tower", action="store_true", help="skip the object-transformer-only fwd+bwd timing")
@@ -212,6 +214,9 @@ def main():
     Fn.OVERLAP_WGRAD = int(a.overlap_wgrad)
     if a.p8 >= 0:
         ops.call("dvlp_gemm_p8_mode", a.p8)
+    for kv in a.knob:
+        name, val = kv.split("=")
+        ops.call(name, int(val))
     arena = ParamArena(model, bf16_shadow=(a.dtype == "bf16"))
     opt = FusedAdamW(arena, lr=1e-5)
     loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")

@@ -31,6 +31,8 @@ struct XLayout {
     int64_t Bi, Bj, G, W, Gp, Wp, es;   // es = element size
     int64_t off_chat, off_qhat, off_S, off_P1, off_P2, off_wc, off_wc2, off_st1, off_st2, off_dP1, off_dP2, off_dchat, off_dqhat,
         off_dirc, off_dirq, off_rinv, off_cinv, off_rpart, off_cpart, total;
+    int64_t off_T, off_kq, off_dkq, off_u2, off_nc;      // Gram form: P2 Kq [Bj][Bi*G][Wp], Kq / dKq [Bj][Wp][Wp], u [Bj][Bi][G] f32, |C^| [Bi][G] f32
+    bool gram;
 };
 static size_t pair_lds(int64_t G, int64_t W, int bwd);
 static bool g_force_general = false;
@@ -46,6 +48,18 @@ static bool x_fused(int dtype, int64_t G, int64_t W, int bwd) {
     return g_fused && !g_force_general && dtype == DVLP_BF16 && !bwd && dvlp_xfused_ok(G, W);
 }
 static bool x_general(int64_t G, int64_t W) { return g_force_general || pair_lds(G, W, 1) > 160 * 1024; }
+// Gram form of the text->image direction (bf16 training path with the per-pair LDS tile): the weighted contexts wc2_g = sum_w P2[g,w] Q^_w
+// ([Bj][Bi][G][d]: 604 MB at B = 64) are never formed.  With unit rows, cos(wc2_g, C_g) = u_g / (sqrt(v_g) |C^_g|),
+//   u_g = wc2_g . C^_g = sum_w P2[g,w] S_raw[g,w]      (S_raw = C^ Q^^T, recovered from the stored LeakyReLU tile: slope 0.1 is invertible)
+//   v_g = |wc2_g|^2   = P2_g Kq P2_g^T,  Kq = Q^ Q^^T  (one W x W Gram matrix per caption)
+// and backward, with alpha_g = dcos_g / (|wc2_g| |C^_g|), beta_g = dcos_g cos_g / |wc2_g|^2:
+//   dP2[g,w] = alpha_g S_raw[g,w] - beta_g (P2 Kq)[g,w],   dS_raw[g,w] += alpha_g P2[g,w],   dQ^ -= ((beta P2)^T P2) Q^.
+// Replaces two [.,d]-wide batched products, the wc2 half of the cosine passes and two backward products by one [Bi*G, W] x [W, W]
+// product per caption, two passes over [B,B,G,W] tiles that exist anyway, and W x W products.
+static int g_gram = getenv("DVLP_XATTN_NO_GRAM") ? 0 : 1;
+extern "C" int dvlp_xattn_gram(int on) { g_gram = on; return DVLP_OK; }
+static int g_xbwd_packed_fwd();       // (defined below: the Gram form needs the bf16 backward kernel)
+static bool x_gram(int dtype, int64_t G, int64_t W) { return g_gram && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G <= 64 * 6; }
 
 static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
     XLayout L{};
@@ -58,12 +72,20 @@ static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, 
     L.off_P1 = take(Bi * Bj * L.Wp * L.Gp * L.es);
     L.off_P2 = take(Bj * Bi * G * L.Wp * L.es);
     L.off_wc = take(Bi * Bj * L.Wp * XD * L.es);
-    L.off_wc2 = take(Bj * Bi * G * XD * L.es);
+    L.gram = x_gram(dtype, G, W);
+    L.off_wc2 = take(L.gram ? 0 : Bj * Bi * G * XD * L.es);
+    if (L.gram) {
+        L.off_T = take(Bj * Bi * G * L.Wp * L.es);
+        L.off_kq = take(Bj * L.Wp * L.Wp * L.es);
+        L.off_dkq = take(Bj * L.Wp * L.Wp * L.es);
+        L.off_u2 = take(Bj * Bi * G * 4);
+        L.off_nc = take(Bi * G * 4);
+    }
     L.off_st1 = take(Bi * Bj * L.Wp * 2 * 4);
     L.off_st2 = take(Bj * Bi * G * 2 * 4);
     if (bwd) {
         L.off_dP1 = take(Bi * Bj * L.Wp * L.Gp * L.es);
-        L.off_dP2 = take(Bj * Bi * G * L.Wp * L.es);
+        L.off_dP2 = take(L.gram ? 0 : Bj * Bi * G * L.Wp * L.es);
         L.off_dchat = take(Bi * G * XD * L.es);
         L.off_dqhat = take(Bj * L.Wp * XD * L.es);
         L.off_dirc = take(Bi * G * XD * 4);
@@ -108,7 +130,8 @@ template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&o)[
 
 // hat[row'] = raw[row] / (|raw[row]| + 1e-8); rows are remapped (r / inner) * inner_p + r % inner, pad rows zeroed
 template <typename T>
-__global__ __launch_bounds__(256) void xprep_kernel(int64_t outer, int64_t inner, int64_t inner_p, const T* __restrict__ raw, T* __restrict__ hat) {
+__global__ __launch_bounds__(256) void xprep_kernel(int64_t outer, int64_t inner, int64_t inner_p, const T* __restrict__ raw, T* __restrict__ hat,
+                                                    float* __restrict__ nrm = nullptr /* |hat row| as stored (rounded to T), or null */) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= outer * inner_p) return;
@@ -121,6 +144,13 @@ __global__ __launch_bounds__(256) void xprep_kernel(int64_t outer, int64_t inner
         for (int j = 0; j < 4; ++j) v[j] = v[j] / n;
     }
     st4<T>(hat + r * XD + lane * 4, v);
+    if (nrm) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float t = to_f(from_f<T>(v[j])); q += t * t; }
+        q = wave_sum(q);
+        if (lane == 0) nrm[r] = sqrtf(q);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -133,6 +163,11 @@ struct PairArgs {
     float lam;
     int gate;
     int stop;                     // timing ablation (0 in production): leave the backward kernel after stage `stop`
+    // Gram form (see x_gram): forward writes u2 [Bj][Bi][G]; backward reads T = P2 Kq in place of dP2, (alpha, beta) per row from ab,
+    // and leaves beta P2 in T
+    float* u2;
+    void* T;
+    const float* ab;
 };
 
 constexpr int XT = 1024;     // threads per pair workgroup: 16 waves share one S_ij tile (the tile caps residency at 1 block/CU)
@@ -287,13 +322,20 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
         const int g = g0 + half;
         const bool ok = g < a.G;
         const int gc = ok ? g : a.G - 1;
-        float e[NKW], pp[NKW], s;
+        float e[NKW], pp[NKW], sv[NKW], s;
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; e[k] = w < a.W ? a.lam * (Ssm[gc * a.Wq + w] * ci[k] + mc[k]) : 0.f; }
+        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = w < a.W ? a.lam * (sv[k] * ci[k] + mc[k]) : 0.f; }
         focal_softmax<NKW, false, sizeof(T) == 2>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
         if (ok) {
 #pragma unroll
             for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+        }
+        if (a.u2) {                                 // Gram form: u_g = sum_w P2[g,w] S_raw[g,w] with the probabilities as stored
+            float uu = 0.f;
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) uu += to_f(from_f<T>(pp[k])) * (sv[k] > 0.f ? sv[k] : 10.f * sv[k]);
+            uu = half_sum(uu);
+            if (ok && hl == 0) a.u2[((int64_t)j * a.Bi + i) * a.G + g] = uu;
         }
     }
 }
@@ -437,7 +479,9 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
     float* rpart = coldot + a.W;                // [NW][G]        per-wave partial <dA, S> over the words the wave owned
     float* qpart = rpart + NW * a.G;            // [2 NW][32 NKW] per-half partial <dA2, S> over the regions the half owned
     const bf16* D1 = (const bf16*)a.dP1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;
-    const bf16* D2 = (const bf16*)a.dP2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;
+    const bool gram = a.T != nullptr;
+    const bf16* D2 = (const bf16*)(gram ? a.T : a.dP2) + ((int64_t)j * a.Bi + i) * a.G * a.Wp;   // Gram form: T = P2 Kq in place of dP2
+    const float* ab = gram ? a.ab + ((int64_t)j * a.Bi + i) * a.G * 2 : nullptr;
     // prefetched rows stay packed (two bf16 per register) until their pass: unpacked they would not fit 128 VGPRs
     const unsigned short* D1u = (const unsigned short*)D1; const unsigned short* D2u = (const unsigned short*)D2;
     auto unpack = [](const uint32_t* p, int k) { return __uint_as_float((k & 1) ? (p[k >> 1] & 0xffff0000u) : (p[k >> 1] << 16)); };
@@ -524,8 +568,14 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
             }
             focal_softmax<NKW, false, true>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
             float dpp[NKW], d1 = 0.f;
+            float alpha = 0.f, beta = 0.f;
+            if (gram) { alpha = ab[2 * gc]; beta = ab[2 * gc + 1]; }
 #pragma unroll
-            for (int k = 0; k < NKW; ++k) { dpp[k] = unpack(d2p[it], k); d1 += dpp[k] * pp[k]; }
+            for (int k = 0; k < NKW; ++k) {
+                dpp[k] = unpack(d2p[it], k);
+                if (gram) dpp[k] = alpha * (sv[k] > 0.f ? sv[k] : 10.f * sv[k]) - beta * dpp[k];      // dP2 = alpha S_raw - beta (P2 Kq)
+                d1 += dpp[k] * pp[k];
+            }
             d1 = half_sum(d1);
             const float is = __builtin_amdgcn_rcpf(s);
             float d2 = 0.f;
@@ -537,6 +587,14 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
                 const float dA = ok ? a.lam * e[k] * (dpp[k] - d2) : 0.f;
                 d2v[it][k] = dA * ci[k];
                 cd[k] += dA * sv[k];
+                if (gram) {
+                    // u depends on S_raw directly: dS_raw += alpha P2 (scaled so that the LeakyReLU' factor of the last pass leaves it as it
+                    // is), and beta P2 replaces T for the dKq product
+                    const float pk = (float)(bf16)pp[k];
+                    if (ok) d2v[it][k] += alpha * pk * (sv[k] > 0.f ? 1.f : 10.f);
+                    const int w = hl + 32 * k;
+                    if (ok && w < a.W) ((bf16*)a.T)[(((int64_t)j * a.Bi + i) * a.G + g) * a.Wp + w] = (bf16)(beta * pk);
+                }
             }
         }
 #pragma unroll
@@ -821,6 +879,7 @@ struct CosArgs {
     const float* dscores;
     float *dirc, *dirq;
     int Bi, Bj, G, W, Wp;
+    const float* nc;            // Gram form: |C^ row| [Bi][G]; then st2 holds (u, |wc2|) on entry of the forward kernel and wc2 is unused
 };
 
 // (dot, |b|) of a raw row with a context row; returns cosine
@@ -870,7 +929,12 @@ __global__ __launch_bounds__(256) void xcos_fwd_kernel(CosArgs a) {
     {
         const int64_t r1 = ((int64_t)i * a.Bj + j) * a.Wp, r2 = ((int64_t)j * a.Bi + i) * a.G;
         sweep((const T*)a.Qraw + (int64_t)j * a.W * XD, (const T*)a.wc + r1 * XD, a.st1 + r1 * 2, a.W, acc1);
-        sweep((const T*)a.Craw + (int64_t)i * a.G * XD, (const T*)a.wc2 + r2 * XD, a.st2 + r2 * 2, a.G, acc2);
+        if (!a.nc) sweep((const T*)a.Craw + (int64_t)i * a.G * XD, (const T*)a.wc2 + r2 * XD, a.st2 + r2 * 2, a.G, acc2);
+        else {                                          // Gram form: (u, |wc2|) are there already
+            float part = 0.f;
+            for (int g = threadIdx.x; g < a.G; g += 256) part += a.st2[(r2 + g) * 2] / fmaxf(a.nc[(int64_t)i * a.G + g] * a.st2[(r2 + g) * 2 + 1], 1e-8f);
+            acc2 = wave_sum(part);
+        }
     }
     if (lane == 0) red[wid] = acc1 / (float)a.W + acc2 / (float)a.G;       // means include padded rows (loss.py:318, 327)
     __syncthreads();
@@ -940,6 +1004,34 @@ __global__ __launch_bounds__(256) void xcos_bwd_c_kernel(CosArgs a) {
     *(float4*)(a.dirc + row * XD + lane * 4) = make_float4(dir[0], dir[1], dir[2], dir[3]);
 }
 
+// Gram form.  v_g = sum_w P2[g,w] (P2 Kq)[g,w]; st2 <- (u_g, sqrt(v_g)).  16 lanes per row (8 elements each), 16 rows per workgroup.
+__global__ __launch_bounds__(256) void xgram_v_kernel(int64_t rows, int Wp, const bf16* __restrict__ P2, const bf16* __restrict__ T, const float* __restrict__ u2,
+                                                      float* __restrict__ st2) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+    float q = 0.f;
+    if (r < rows && sub * 8 < Wp) {
+        float p[8], t[8];
+        ld8<bf16>(P2 + r * Wp + sub * 8, p); ld8<bf16>(T + r * Wp + sub * 8, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += p[e] * t[e];
+    }
+    q = row16_sum(q);
+    if (r < rows && sub == 0) { st2[r * 2] = u2[r]; st2[r * 2 + 1] = sqrtf(fmaxf(q, 0.f)); }
+}
+// backward of the cosine for the Gram form: st2 (u, |wc2|) -> (alpha, beta) per (j, i, g) row
+__global__ __launch_bounds__(256) void xgram_ab_kernel(int Bi, int Bj, int G, const float* __restrict__ dscores, const float* __restrict__ nc, float* __restrict__ st2) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (j * Bi + i) * G + g
+    if (r >= (int64_t)Bj * Bi * G) return;
+    const int g = (int)(r % G), i = (int)((r / G) % Bi), j = (int)(r / ((int64_t)G * Bi));
+    const float dot = st2[r * 2], nw = st2[r * 2 + 1], nq = nc[(int64_t)i * G + g];
+    const float dcos = dscores[(int64_t)i * Bj + j] / (float)G;
+    const float den = nq * nw;
+    float ka = 0.f, kc = 0.f;
+    if (den > 1e-8f) { ka = dcos / den; kc = dcos * dot / (den * nw * nw); }
+    st2[r * 2] = ka; st2[r * 2 + 1] = kc;
+}
+
 // x^ = x / (n + eps):  dx = dx^/(n+eps) - x <dx^, x> / ((n+eps)^2 n)  + direct term
 template <typename T>
 __global__ __launch_bounds__(256) void xprep_bwd_kernel(int64_t outer, int64_t inner, int64_t inner_p, const T* __restrict__ raw,
@@ -982,6 +1074,7 @@ static void launch_pair_w(bool bwd, int nkw, dim3 grid, size_t lds, hipStream_t 
 static int g_xstop = 0;
 extern "C" int dvlp_xattn_bwd_stop(int stage) { g_xstop = stage; return DVLP_OK; }
 static int g_xbwd_packed = 1;    // bf16 backward: 1 = xsoftmax_bwd_bf16_kernel, 0 = the generic kernel (A/B, tests)
+static int g_xbwd_packed_fwd() { return g_xbwd_packed; }
 extern "C" int dvlp_xattn_bwd_variant(int packed) { g_xbwd_packed = packed; return DVLP_OK; }
 static size_t pair_lds_bf16_bwd(int64_t G, int64_t W) {
     const int64_t Wq = W | 1;
@@ -1075,11 +1168,12 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
 #define DT(K, ...) do { if (dtype == DVLP_F32) hipLaunchKernelGGL(K<float>, __VA_ARGS__); else hipLaunchKernelGGL(K<bf16>, __VA_ARGS__); } while (0)
 #define TP(p) (dtype == DVLP_F32 ? (void*)(p) : (void*)(p))
     if (dtype == DVLP_F32) {
-        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (float*)chat);
-        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (float*)qhat);
+        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (float*)chat, (float*)nullptr);
+        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (float*)qhat, (float*)nullptr);
     } else {
-        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const bf16*)Craw, (bf16*)chat);
-        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (bf16*)qhat);
+        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const bf16*)Craw, (bf16*)chat,
+                           L.gram ? (float*)(ws + L.off_nc) : (float*)nullptr);
+        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (bf16*)qhat, (float*)nullptr);
     }
     // S [Bi*G x Bj*Wp] = LeakyReLU(Chat [Bi*G x d] . Qhat^T): every pair at once is ONE plain product (Qhat is shared by all videos),
     // which the 256-row kernel takes (1872 tiles); as Bi batches of G = 288 rows it ran on the 128-row kernel at half the rate
@@ -1088,6 +1182,7 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
     pa.lam = lam; pa.gate = gate;
+    pa.u2 = L.gram ? (float*)(ws + L.off_u2) : nullptr;
     if (!general) {
         if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 0);
@@ -1111,13 +1206,23 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     hipStream_t s2 = t_xfork.begin(st);
     XG(dtype, 0, 1, Bj * Wp, XD, G, P1, Gp, chat, XD, wc, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, G * XD,
        Bj * Wp * XD, 0, 0, stream);
-    // wc2[j] [(Bi*G) x d] = P2[j] [(Bi*G) x Wp] . Qhat_j [Wp x d]
-    XG(dtype, 0, 1, Bi * G, XD, Wp, P2, Wp, qhat, XD, wc2, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Wp * XD,
-       Bi * G * XD, 0, 0, (void*)s2);
+    if (!L.gram) {
+        // wc2[j] [(Bi*G) x d] = P2[j] [(Bi*G) x Wp] . Qhat_j [Wp x d]
+        XG(dtype, 0, 1, Bi * G, XD, Wp, P2, Wp, qhat, XD, wc2, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Wp * XD,
+           Bi * G * XD, 0, 0, (void*)s2);
+    } else {
+        // Gram form (x_gram): Kq[j] = Qhat_j Qhat_j^T, T[j] = P2[j] Kq[j], v = rowsum(P2 o T); st2 <- (u, sqrt(v))
+        void *kq = ws + L.off_kq, *T = ws + L.off_T;
+        XG(dtype, 0, 0, Wp, Wp, XD, qhat, XD, qhat, XD, kq, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Wp * XD, Wp * XD, Wp * Wp, 0, 0, (void*)s2);
+        XG(dtype, 0, 0, Bi * G, Wp, Wp, P2, Wp, kq, Wp, T, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Wp * Wp, Bi * G * Wp, 0, 0, (void*)s2);
+        hipLaunchKernelGGL(xgram_v_kernel, dim3((unsigned)cdiv(Bj * Bi * G, 16)), b256, 0, s2, Bj * Bi * G, (int)Wp, (const bf16*)P2, (const bf16*)T,
+                           (const float*)(ws + L.off_u2), (float*)(ws + L.off_st2));
+    }
     t_xfork.end(st, s2);
     CosArgs ca{};
     ca.Craw = Craw; ca.Qraw = Qraw; ca.wc = wc; ca.wc2 = wc2; ca.st1 = (float*)(ws + L.off_st1); ca.st2 = (float*)(ws + L.off_st2);
     ca.scores = scores; ca.Bi = (int)Bi; ca.Bj = (int)Bj; ca.G = (int)G; ca.W = (int)W; ca.Wp = (int)Wp;
+    ca.nc = L.gram ? (const float*)(ws + L.off_nc) : nullptr;
     DT(xcos_fwd_kernel, dim3((unsigned)Bj, (unsigned)Bi), b256, 0, st, ca);
     return dvlp_launch_status();
 }
@@ -1145,18 +1250,27 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     ca.dscores = dscores; ca.dirc = dirc; ca.dirq = dirq; ca.Bi = (int)Bi; ca.Bj = (int)Bj; ca.G = (int)G; ca.W = (int)W; ca.Wp = (int)Wp;
     hipStream_t s2 = t_xfork.begin(st);
     DT(xcos_bwd_q_kernel, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, ca);       // wc  <- d wc
-    DT(xcos_bwd_c_kernel, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, s2, ca);        // wc2 <- d wc2
+    if (!L.gram) DT(xcos_bwd_c_kernel, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, s2, ca);        // wc2 <- d wc2
+    else {
+        // Gram form: per-row (alpha, beta) in place of d wc2; the direct term on C travels through dS_raw (+ a radial part that
+        // the normalisation's backward removes), so the direct-term buffer is zero
+        hipLaunchKernelGGL(xgram_ab_kernel, dim3((unsigned)cdiv(Bj * Bi * G, 256)), b256, 0, s2, (int)Bi, (int)Bj, (int)G, dscores,
+                           (const float*)(ws + L.off_nc), (float*)(ws + L.off_st2));
+        (void)hipMemsetAsync(dirc, 0, (size_t)Bi * G * XD * 4, s2);
+    }
     // dP1[i] [(Bj*Wp) x G] = dwc[i] [(Bj*Wp) x d] . Chat_i^T
     XG(dtype, 0, 0, Bj * Wp, G, XD, wc, XD, chat, XD, dP1, Gp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * XD, G * XD,
        Bj * Wp * Gp, 0, 0, stream);
-    // dP2[j] [(Bi*G) x Wp] = dwc2[j] [(Bi*G) x d] . Qhat_j^T
-    XG(dtype, 0, 0, Bi * G, Wp, XD, wc2, XD, qhat, XD, dP2, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * XD, Wp * XD,
-       Bi * G * Wp, 0, 0, (void*)s2);
+    // dP2[j] [(Bi*G) x Wp] = dwc2[j] [(Bi*G) x d] . Qhat_j^T   (Gram form: formed inside the softmax backward from S_raw and T)
+    if (!L.gram)
+        XG(dtype, 0, 0, Bi * G, Wp, XD, wc2, XD, qhat, XD, dP2, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * XD, Wp * XD,
+           Bi * G * Wp, 0, 0, (void*)s2);
     t_xfork.end(st, s2);
     PairArgs pa{};
     pa.S = S; pa.P1 = P1; pa.P2 = P2; pa.dP1 = dP1; pa.dP2 = dP2; pa.mimg = mimg; pa.mcap = mcap;
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
     pa.lam = lam; pa.gate = gate; pa.stop = g_xstop;
+    if (L.gram) { pa.T = ws + L.off_T; pa.ab = (const float*)(ws + L.off_st2); }
     if (!general) {
         if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 1);
@@ -1186,10 +1300,18 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     XG(dtype, 0, 1, G, XD, Bj * Wp, S, Bj * Wp, qhat, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bi, G * Bj * Wp, 0,
        G * XD, 0, 0, stream);
     // dQhat_j [Wp x d] = P2[j]^T [Wp x Bi*G] . dwc2[j] [Bi*G x d]  +  dSraw[:, :, j, :]^T [Wp x Bi*G] . Chat [Bi*G x d]
-    XG(dtype, 1, 1, Wp, XD, Bi * G, P2, Wp, wc2, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Bi * G * XD,
-       Wp * XD, 0, 0, (void*)s2);
-    XG(dtype, 1, 1, Wp, XD, Bi * G, S, Bj * Wp, chat, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bj, Wp, 0, Wp * XD, 0,
-       0, (void*)s2);
+    if (!L.gram) {
+        XG(dtype, 1, 1, Wp, XD, Bi * G, P2, Wp, wc2, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Bi * G * XD,
+           Wp * XD, 0, 0, (void*)s2);
+        XG(dtype, 1, 1, Wp, XD, Bi * G, S, Bj * Wp, chat, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bj, Wp, 0, Wp * XD, 0,
+           0, (void*)s2);
+    } else {
+        // Gram form: dQhat_j = dSraw[:, :, j, :]^T Chat  -  ((beta P2)[j]^T P2[j]) Qhat_j      (beta P2 was left in T by the softmax backward)
+        void *T = ws + L.off_T, *dkq = ws + L.off_dkq;
+        XG(dtype, 1, 1, Wp, XD, Bi * G, S, Bj * Wp, chat, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Wp, 0, Wp * XD, 0, 0, (void*)s2);
+        XG(dtype, 1, 1, Wp, Wp, Bi * G, T, Wp, P2, Wp, dkq, Wp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bj, Bi * G * Wp, Bi * G * Wp, Wp * Wp, 0, 0, (void*)s2);
+        XG(dtype, 0, 1, Wp, XD, Wp, dkq, Wp, qhat, XD, dqhat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, -1.f, Bj, Wp * Wp, Wp * XD, Wp * XD, 0, 0, (void*)s2);
+    }
     t_xfork.end(st, s2);
     if (dtype == DVLP_F32) {
         hipLaunchKernelGGL(xprep_bwd_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (const float*)dchat, dirc, (float*)dC);

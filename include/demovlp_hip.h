@@ -160,6 +160,10 @@ int dvlp_xattn_fused_mode(int mode);
 /* bf16 backward of the per-pair softmax stage: 1 (default) keeps both intermediate tiles on chip (LDS low halves / registers),
    0 runs the generic kernel that round-trips them through the workspace -- for A/B measurements and tests */
 int dvlp_xattn_bwd_variant(int packed);
+/* 1 (default): bf16 pairs that fit the per-pair LDS tile use the Gram form of the text->image direction -- cos(wc2_g, C_g) from
+   u_g = sum_w P2 S_raw and v_g = P2_g (Q^ Q^^T) P2_g^T, so the [Bj][Bi][G][d] weighted contexts are never formed (forward or backward);
+   0: the weighted contexts are materialised as in the reference -- for A/B measurements and tests */
+int dvlp_xattn_gram(int on);
 /* 1: the text->image half of the local loss (its contractions and cosine passes) is issued on an internal side stream beside the
    image->text half between the softmax stages (fork / join by events, capturable); 0 (default): everything on the caller's stream */
 int dvlp_xattn_parallel_halves(int on);
