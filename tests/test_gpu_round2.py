@@ -532,7 +532,7 @@ def test_fused_local_loss_forward_vs_oracle(B, G, W, gate):
 
 @pytest.mark.parametrize("B,G,W", [(2, 288, 99), (3, 240, 37), (3, 30, 99), (2, 288, 112), (3, 100, 7), (2, 16, 128)])
 @pytest.mark.parametrize("gate", [True, False])
-def test_local_loss_backward_bf16_on_chip_tiles_vs_generic_and_oracle(B, G, W, gate):
+def test_local_loss_bf16_on_chip_tiles_and_gram_form_vs_generic_and_oracle(B, G, W, gate):
     """bf16 backward of the per-pair softmax stage with both intermediate tiles on chip (xsoftmax_bwd_bf16_kernel) against the generic
     kernel that round-trips them through the workspace (same math, one bf16 rounding fewer on the text->image tile) and against the
     fp64 oracle's autograd gradient on the same bf16-rounded inputs (1e-1 of the largest gradient: tests/test_gpu_kernels.py's bf16
@@ -554,21 +554,31 @@ def test_local_loss_backward_bf16_on_chip_tiles_vs_generic_and_oracle(B, G, W, g
     Cr, Qr = C.double().cpu().requires_grad_(True), Q.double().cpu().requires_grad_(True)
     sc = orc.xattn_scores_batched(Cr, Qr, torch.from_numpy(m_img).double(), torch.from_numpy(m_cap).double(), 20.0, gate)
     (sc * torch.from_numpy(dsc).double()).sum().backward()
-    res = {}
+    # mode 0: generic kernels, weighted contexts materialised (the reference's structure); 1: bf16 kernels, contexts materialised;
+    # 2: bf16 kernels + Gram form of the text->image direction (the default): cos(wc2_g, C_g) from u = sum_w P2 S_raw and
+    # v = P2 (Q Q^T) P2^T, backward from per-row (alpha, beta) -- no [Bj][Bi][G][d] tensor in either pass
+    res, sco = {}, {}
     try:
-        for mode in (0, 1):
-            ops.call("dvlp_xattn_bwd_variant", mode)
-            _, ws = ops.xattn_fwd(C, Q, t(m_img), t(m_cap), 20.0, gate, True)
+        for mode in (0, 1, 2):
+            ops.call("dvlp_xattn_bwd_variant", int(mode > 0))
+            ops.call("dvlp_xattn_gram", int(mode == 2))
+            scores, ws = ops.xattn_fwd(C, Q, t(m_img), t(m_cap), 20.0, gate, True)
+            sco[mode] = scores.cpu().numpy()
             dC, dQ = ops.xattn_bwd(C, Q, t(m_img), t(m_cap), 20.0, gate, t(dsc), ws)
             res[mode] = (dC.float().cpu().numpy(), dQ.float().cpu().numpy())
     finally:
         ops.call("dvlp_xattn_bwd_variant", 1)
-    for k, ref in enumerate((Cr.grad.numpy(), Qr.grad.numpy())):
-        scale = np.abs(ref).max()
-        assert np.abs(res[1][k] - res[0][k]).max() <= 2e-2 * scale, (k, np.abs(res[1][k] - res[0][k]).max(), scale)
-        assert np.abs(res[1][k] - ref).max() <= 1e-1 * scale, (k, np.abs(res[1][k] - ref).max(), scale)
-        # the on-chip form is never further from the oracle than the generic one by more than rounding noise
-        assert np.abs(res[1][k] - ref).max() <= np.abs(res[0][k] - ref).max() + 1e-2 * scale
+        ops.call("dvlp_xattn_gram", 1)
+    ref_s = sc.detach().numpy()
+    for mode in (1, 2):
+        assert np.abs(sco[mode] - ref_s).max() < 2e-3, (mode, np.abs(sco[mode] - ref_s).max())
+        assert np.abs(sco[mode] - sco[0]).max() < 2e-3
+        for k, ref in enumerate((Cr.grad.numpy(), Qr.grad.numpy())):
+            scale = np.abs(ref).max()
+            assert np.abs(res[mode][k] - res[0][k]).max() <= 2e-2 * scale, (mode, k, np.abs(res[mode][k] - res[0][k]).max(), scale)
+            assert np.abs(res[mode][k] - ref).max() <= 1e-1 * scale, (mode, k, np.abs(res[mode][k] - ref).max(), scale)
+            # neither form is further from the oracle than the generic one by more than rounding noise
+            assert np.abs(res[mode][k] - ref).max() <= np.abs(res[0][k] - ref).max() + 1e-2 * scale
 
 
 # ---------------------------------------------------------------------------------------------------------------------
