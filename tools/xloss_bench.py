@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from demovlp_amd import ops  # noqa: E402
 
 B, G, W = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 288, 99)
+ONLY = int(os.environ["XLOSS_ONLY"]) if "XLOSS_ONLY" in os.environ else None      # profile one variant
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 C = torch.randn(B, G, 256, device=dev, generator=g).bfloat16()
@@ -34,7 +35,7 @@ def med(fn, reps=7):
 
 
 res = {}
-for variant in (0, 1, 2):                 # 0 generic kernels, 1 bf16 kernels with the weighted contexts materialised, 2 bf16 kernels + Gram form
+for variant in ((ONLY,) if ONLY is not None else (0, 1, 2)):                 # 0 generic kernels, 1 bf16 kernels with the weighted contexts materialised, 2 bf16 kernels + Gram form
     ops.call("dvlp_xattn_bwd_variant", int(variant > 0))
     ops.call("dvlp_xattn_gram", int(variant == 2))
     sc, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True)
@@ -51,7 +52,7 @@ for variant in (0, 1, 2):                 # 0 generic kernels, 1 bf16 kernels wi
     print(f"variant {variant}: forward {tf:8.1f} us   backward {tb:8.1f} us")
 ops.call("dvlp_xattn_bwd_variant", 1)
 ops.call("dvlp_xattn_gram", 1)
-for k, name in enumerate(("scores", "dC", "dQ")):
+for k, name in enumerate(("scores", "dC", "dQ") if ONLY is None else ()):
     d = (res[1][k] - res[0][k]).abs().max().item()
     d2 = (res[2][k] - res[0][k]).abs().max().item()
     print(f"{name}: max |bf16 kernels - generic| = {d:.3g}, max |Gram form - generic| = {d2:.3g} (max |generic| = {res[0][k].abs().max().item():.3g})")
