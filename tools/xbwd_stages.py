@@ -18,10 +18,10 @@ mi = torch.zeros(B, G, device=dev)
 mc = torch.zeros(B, W, device=dev)
 mc[:, 30:] = -100.0
 dsc = torch.randn(B, B, device=dev, generator=g)
-_, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True)
-keep = ws.clone()
-for variant, stops in ((0, (0,)), (1, (0, 1, 2, 3))):
+for variant, stops in ((0, (0,)), (1, (0, 6, 5, 1, 2, 3))):
     ops.call("dvlp_xattn_bwd_variant", variant)
+    _, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True)          # the workspace layout depends on the variant
+    keep = ws.clone()
     for stop in stops:
         ops.call("dvlp_xattn_bwd_stop", stop)
         ts = []
