@@ -96,39 +96,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
-// bf16 epilogues: GELU through the Abramowitz-Stegun 7.1.26 rational form of erf (|error| <= 1.5e-7 absolute, two orders
-// below bf16 resolution): ONE v_exp_f32 shared by the erf tail and the Gaussian of the derivative, one v_rcp_f32, ~10 FMAs.
-// The libm erff/expf pair these replace cost ~100 VALU instructions per element and made the fc1 backward GEMM (57 M
-// outputs per layer) spend as long in its epilogue as in its MFMAs.  The fp32 kernels keep erff/expf (1e-4 parity path).
-__device__ __forceinline__ void gelu_fast_parts(float x, float& Phi, float& E) {
-    const float ax = fabsf(x);
-    E = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);                 // exp(-x^2 / 2)
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189867f, ax, 1.0f));      // 1 / (1 + p |x| / sqrt(2)), p = 0.3275911
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float q = 0.5f * poly * t * E;                                          // upper tail 1 - Phi(|x|)
-    Phi = x >= 0.f ? 1.0f - q : q;
-}
-__device__ __forceinline__ float gelu_fast(float x) {
-    float Phi, E;
-    gelu_fast_parts(x, Phi, E);
-    return x * Phi;
-}
-__device__ __forceinline__ float gelu_fast_grad(float x) {
-    float Phi, E;
-    gelu_fast_parts(x, Phi, E);
-    return fmaf(x * 0.39894228040143267794f, E, Phi);
-}
-
-// Polynomial forms for the 256-row bf16 GEMM epilogue, two elements at a time (v_pk_fma_f32): the transcendental form above is
-// 2 quarter-rate + ~14 full-rate VALU instructions per element, and with one workgroup per CU nothing overlaps them -- the fc1
-// forward / fc2 backward products spent ~25 % of their time there.  Odd minimax polynomials in z = clamp(x / A, -1, 1)
+// GELU / GELU' of the bf16 GEMM epilogues (every bf16 kernel, vector and scalar paths alike), two elements at a time
+// (v_pk_fma_f32).  History: libm erff / expf cost ~100 VALU per element (the fc1 backward GEMM spent as long in its epilogue as in
+// its MFMAs); an Abramowitz-Stegun rational erf with one shared v_exp_f32 and one v_rcp_f32 (round 1) still was 2 quarter-rate +
+// ~14 full-rate instructions per element, and with one workgroup per CU nothing overlaps them -- the fc1 forward / fc2 backward
+// products spent ~25 % of their time there.  Odd minimax polynomials in z = clamp(x / A, -1, 1)
 // (tools/fit_gelu_poly.py, errors include the fp32 Horner evaluation):
 //   Phi(x)   = 0.5 + z P(z^2), A = 4.0, |err| <= 6e-6 inside [-4, 4] (gelu: 2.3e-5), tails pinned at Phi(+-4)
 //   gelu'(x) = 0.5 + z Q(z^2), A = 4.5, |err| <= 1.8e-4
-// both far below the bf16 resolution of the values they produce.
+// both far below the bf16 resolution of the values they produce.  The fp32 kernels keep erff / expf (1e-4 parity path).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float GELU_PHI_C[9] = {1.595690840e+00f, -4.250278161e+00f, 1.011453720e+01f, -1.857818477e+01f, 2.592817434e+01f, -2.640316869e+01f, 1.822784375e+01f, -7.519930336e+00f, 1.385288103e+00f};
 constexpr float GELU_DGELU_C[10] = {3.589317633e+00f, -2.414135244e+01f, 1.081506568e+02f, -3.294218669e+02f, 7.116908195e+02f, -1.091321666e+03f, 1.154870954e+03f, -7.967612061e+02f, 3.208072879e+02f, -5.696292942e+01f};

@@ -40,12 +40,12 @@ __device__ __attribute__((noinline)) void epi_store(const Epi& e, T* __restrict_
     if (e.bias) v += e.bias[n];
     if (e.flags & EPI_GELU) {
         ((T*)e.aux)[m * e.ldaux + n] = from_f<T>(v);
-        v = sizeof(T) == 2 ? gelu_fast(v) : gelu_erf(v);
+        v = sizeof(T) == 2 ? gelu_poly2((f32x2){v, 0.f})[0] : gelu_erf(v);       // bf16: the same polynomial as the vector epilogues
     }
     if (e.flags & EPI_LEAKY) v = v > 0.f ? v : 0.1f * v;
     if (e.flags & EPI_GELU_BWD) {
         const float h = to_f(((const T*)e.aux)[m * e.ldaux + n]);
-        v *= sizeof(T) == 2 ? gelu_fast_grad(h) : gelu_erf_grad(h);
+        v *= sizeof(T) == 2 ? gelu_grad_poly2((f32x2){h, 0.f})[0] : gelu_erf_grad(h);
     }
     if (e.flags & EPI_RELU_BWD) v = to_f(((const T*)e.aux)[m * e.ldaux + n]) > 0.f ? v : 0.f;
     if (e.res) v += to_f(((const T*)e.res)[m * e.ldres + n]);
@@ -77,7 +77,9 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
     if (e.flags & EPI_GELU) {
         bf16x8 pre;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { pre[t] = (bf16)v[t]; v[t] = gelu_fast(v[t]); }
+        for (int t = 0; t < 8; ++t) pre[t] = (bf16)v[t];
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) { const f32x2 y = gelu_poly2((f32x2){v[t], v[t + 1]}); v[t] = y[0]; v[t + 1] = y[1]; }   // as in epi_store8_pre
         *(bf16x8*)((bf16*)e.aux + m * e.ldaux + n) = pre;
     }
     if (e.flags & EPI_LEAKY) {
@@ -86,10 +88,15 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
     }
     if (e.flags & (EPI_GELU_BWD | EPI_RELU_BWD)) {
         const bf16x8 a = *(const bf16x8*)((const bf16*)e.aux + m * e.ldaux + n);
+        if (e.flags & EPI_GELU_BWD) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float h = (float)a[t];
-            v[t] = (e.flags & EPI_GELU_BWD) ? v[t] * gelu_fast_grad(h) : (h > 0.f ? v[t] : 0.f);
+            for (int t = 0; t < 8; t += 2) {
+                const f32x2 d = gelu_grad_poly2((f32x2){(float)a[t], (float)a[t + 1]});
+                v[t] *= d[0]; v[t + 1] *= d[1];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = (float)a[t] > 0.f ? v[t] : 0.f;
         }
     }
     if (e.res) {

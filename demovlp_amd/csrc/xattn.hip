@@ -293,7 +293,9 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, half = lane >> 5, hl = lane & 31;
     const int j = blockIdx.x, i = blockIdx.y;
     float* Ssm = sm; float* rn = Ssm + a.G * a.Wq; float* cn = rn + a.G; float* cpart = cn + a.W;
+    if (a.stop == 6) return;                       // timing ablations (0 in production), as in the backward kernel
     pair_load_S<T>(a, i, j, Ssm, rn, cn, cpart);
+    if (a.stop == 1 || a.stop == 5) return;
     T* P1 = (T*)a.P1 + ((int64_t)i * a.Bj + j) * a.Wp * a.Gp;
     T* P2 = (T*)a.P2 + ((int64_t)j * a.Bi + i) * a.G * a.Wp;
     const float* mimg = a.mimg + (int64_t)i * a.G;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
 #pragma unroll
         for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(g < a.G ? pp[k] : 0.f); }
     }
+    if (a.stop == 2) return;
     // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
     float mc[NKW], ci[NKW];
 #pragma unroll
@@ -1185,6 +1188,7 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
     pa.lam = lam; pa.gate = gate;
     pa.u2 = L.gram ? (float*)(ws + L.off_u2) : nullptr;
+    pa.stop = g_xstop;
     if (!general) {
         if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 0);

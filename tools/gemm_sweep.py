@@ -61,9 +61,10 @@ for label, kind, T, N, K in CASES:
         out = torch.empty(N, K, device=dev, dtype=torch.float32)
         fn = lambda: ops.linear_bwd_weight(dy, x, out=out)
     res = []
-    for p8 in (0, 2):
+    for p8 in (0, 2, "w"):                                   # 128 x 128, 256 x 256, 256 x 128 ("wide")
         for S in (0, 1, 2, 3, 4, 6, 8):
-            ops.call("dvlp_gemm_p8_mode", p8)
+            ops.call("dvlp_gemm_p8_mode", 0 if p8 == "w" else p8)
+            ops.call("dvlp_gemm_wide_mode", 2 if p8 == "w" else 0)
             ops.call("dvlp_gemm_force_split", S)
             try:
                 t = bench(fn)
@@ -71,6 +72,7 @@ for label, kind, T, N, K in CASES:
             except Exception as e:  # noqa: BLE001
                 pass
     ops.call("dvlp_gemm_p8_mode", 1)
+    ops.call("dvlp_gemm_wide_mode", 0)
     ops.call("dvlp_gemm_force_split", 0)
     t_auto = bench(fn)
     res.sort()

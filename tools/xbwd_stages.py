@@ -37,3 +37,18 @@ for variant, stops in ((0, (0,)), (1, (0, 6, 5, 1, 2, 3))):
         print(f"variant {variant} stop {stop}: whole backward {sorted(ts)[len(ts) // 2]:8.1f} us")
 ops.call("dvlp_xattn_bwd_stop", 0)
 ops.call("dvlp_xattn_bwd_variant", 1)
+
+# forward kernel (same stops): time of dvlp_xattn_fwd with the softmax kernel cut after each stage
+for stop in (0, 6, 5, 1, 2):
+    ops.call("dvlp_xattn_bwd_stop", stop)
+    ts = []
+    for rep in range(5):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    print(f"forward stop {stop}: whole forward {sorted(ts)[len(ts) // 2]:8.1f} us")
+ops.call("dvlp_xattn_bwd_stop", 0)
