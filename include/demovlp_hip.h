@@ -87,6 +87,8 @@ int dvlp_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */
 int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,
                        void* y_relu, float* mean, float* rstd, void* stream);
+/* bf16, D = 768: 1 (default) half a wave per row with 16-byte accesses, 0 the generic row-per-wave kernel -- for A/B measurements */
+int dvlp_layernorm_wide(int on);
 int64_t dvlp_layernorm_bwd_blocks(int64_t M);
 /* dx_colsum (optional): fp32 [D] <- column sums of dx, i.e. the bias gradient of the Linear that dx feeds (nn.Linear backward
    after the LayerNorm's); produced by the same kernel on the deferred path, by a dvlp_colsum pass otherwise */
