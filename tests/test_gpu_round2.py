@@ -374,9 +374,14 @@ def test_bench_rccl_path_in_a_one_rank_group(graph):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, DVLP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
-                        "--no-cpu-baseline", "--graph", str(graph)], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
+           "--graph", str(graph)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:                   # one retry on a fresh port: process-group bring-up on a cold box is the only part not under our control
+        print("first attempt failed:", r.stderr[-3000:])
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); env["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["unit"] == "pairs/s" and out["value"] > 0 and out["scaling"] == "weak"
