@@ -252,19 +252,24 @@ __device__ __forceinline__ void pair_load_S(const PairArgs& a, int i, int j, flo
 // FAST (the bf16 kernels): the entries are lambda (A + mask) with |A| <= 1 and mask <= 0, so `bound` = |lambda| replaces the
 // max pass (one cross-lane reduction and a compare chain per row; exp(e - bound) >= exp(-2 lambda) stays normal), and the two
 // reciprocals are v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division.  The fp32 kernels keep both exact.
-template <int NK, bool FULL, bool FAST>
+// Word-axis slots of a 32-lane half: slot k of lane hl is word hl + 32 k, or -- PAIR, for an even slot count -- word
+// 2 hl + (k & 1) + 64 (k >> 1): a lane then owns adjacent word pairs, and the P2 / T / dS rows move as 4-byte pieces (half the memory
+// instructions of the text->image sweeps; the 2-byte form spends a third of those sweeps issuing them).
+template <bool PAIR> __device__ __forceinline__ int wslot(int hl, int k) { return PAIR ? 2 * hl + (k & 1) + 64 * (k >> 1) : hl + 32 * k; }
+template <int NK, bool FULL, bool FAST, bool PAIR = false>
 __device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], int n, int lid, int gate, float bound, float& s_out) {
     constexpr int STRIDE = FULL ? 64 : 32;
+    auto idx = [&](int k) { return (!FULL && PAIR) ? wslot<true>(lid, k) : lid + STRIDE * k; };
     float m = bound;
     if (!FAST) {
         m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) m = fmaxf(m, lid + STRIDE * k < n ? e[k] : -INFINITY);
+        for (int k = 0; k < NK; ++k) m = fmaxf(m, idx(k) < n ? e[k] : -INFINITY);
         m = FULL ? wave_max(m) : half_max(m);
     }
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) { e[k] = lid + STRIDE * k < n ? __expf(e[k] - m) : 0.f; sum += e[k]; }
+    for (int k = 0; k < NK; ++k) { e[k] = idx(k) < n ? __expf(e[k] - m) : 0.f; sum += e[k]; }
     sum = FULL ? wave_sum(sum) : half_sum(sum);
     const float inv = FAST ? __builtin_amdgcn_rcpf(sum) : 1.f / sum;
     float psum = 0.f;
@@ -319,20 +324,33 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
     }
     if (a.stop == 2) return;
     // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
+    constexpr bool PAIR = NKW % 2 == 0;
     float mc[NKW], ci[NKW];
 #pragma unroll
-    for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; }
+    for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; }
     for (int g0 = 2 * wid; g0 < a.G; g0 += 2 * nw) {
         const int g = g0 + half;
         const bool ok = g < a.G;
         const int gc = ok ? g : a.G - 1;
         float e[NKW], pp[NKW], sv[NKW], s;
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = w < a.W ? a.lam * (sv[k] * ci[k] + mc[k]) : 0.f; }
-        focal_softmax<NKW, false, sizeof(T) == 2>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
+        for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = w < a.W ? a.lam * (sv[k] * ci[k] + mc[k]) : 0.f; }
+        focal_softmax<NKW, false, sizeof(T) == 2, PAIR>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
         if (ok) {
+            if constexpr (PAIR) {
 #pragma unroll
-            for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+                for (int k = 0; k < NKW; k += 2) {              // Wp is a multiple of 8: a pair is inside the row or outside it
+                    const int w = wslot<true>(hl, k);
+                    if (w < a.Wp) {
+                        T two[2] = {from_f<T>(w < a.W ? pp[k] : 0.f), from_f<T>(w + 1 < a.W ? pp[k + 1] : 0.f)};
+                        if constexpr (sizeof(T) == 2) *(uint32_t*)&P2[(int64_t)g * a.Wp + w] = *(const uint32_t*)two;
+                        else *(float2*)&P2[(int64_t)g * a.Wp + w] = *(const float2*)two;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; if (w < a.Wp) P2[(int64_t)g * a.Wp + w] = from_f<T>(w < a.W ? pp[k] : 0.f); }
+            }
         }
         if (a.u2) {                                 // Gram form: u_g = sum_w P2[g,w] S_raw[g,w] with the probabilities as stored
             float uu = 0.f;
@@ -541,23 +559,29 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
         for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.G) rpart[wid * a.G + g] = rd[k]; }
     }
     if (a.stop == 2) return;
+    constexpr bool PAIR = NKW % 2 == 0;         // word slots as adjacent pairs (wslot): rows of dP2 / T / dS move as 4-byte pieces
     uint32_t d2p[IT2][(NKW + 1) / 2];
 #pragma unroll
     for (int it = 0; it < IT2; ++it) {
         const int g = 2 * wid + half + 2 * NW * it;
 #pragma unroll
         for (int k = 0; k < NKW; k += 2) {
-            const int w0 = hl + 32 * k, w1 = w0 + 32;
-            const uint32_t lo = (g < a.G && w0 < a.W) ? D2u[(int64_t)g * a.Wp + w0] : 0u;
-            const uint32_t hi = (k + 1 < NKW && g < a.G && w1 < a.W) ? D2u[(int64_t)g * a.Wp + w1] : 0u;
-            d2p[it][k >> 1] = lo | (hi << 16);
+            if constexpr (PAIR) {                   // slots k, k + 1 are words w, w + 1 (pads of these rows are zero)
+                const int w = wslot<true>(hl, k);
+                d2p[it][k >> 1] = (g < a.G && w < a.W) ? *(const uint32_t*)(D2u + (int64_t)g * a.Wp + w) : 0u;
+            } else {
+                const int w0 = hl + 32 * k, w1 = w0 + 32;
+                const uint32_t lo = (g < a.G && w0 < a.W) ? D2u[(int64_t)g * a.Wp + w0] : 0u;
+                const uint32_t hi = (k + 1 < NKW && g < a.G && w1 < a.W) ? D2u[(int64_t)g * a.Wp + w1] : 0u;
+                d2p[it][k >> 1] = lo | (hi << 16);
+            }
         }
     }
     {
         constexpr int W32 = 32 * NKW;
         float mc[NKW], ci[NKW], cd[NKW];
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; cd[k] = 0.f; }
+        for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; cd[k] = 0.f; }
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
             const int g = 2 * wid + half + 2 * NW * it;
@@ -567,11 +591,11 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
             float e[NKW], pp[NKW], sv[NKW], s;
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
-                const int w = hl + 32 * k;
+                const int w = wslot<PAIR>(hl, k);
                 sv[k] = w < a.W ? __uint_as_float(Su[gc * a.Wq + w] & 0xffff0000u) : 0.f;
                 e[k] = a.lam * (sv[k] * ci[k] + mc[k]);
             }
-            focal_softmax<NKW, false, true>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
+            focal_softmax<NKW, false, true, PAIR>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
             float dpp[NKW], d1 = 0.f;
             float alpha = 0.f, beta = 0.f;
             if (gram) { alpha = ab[2 * gc]; beta = ab[2 * gc + 1]; }
@@ -597,13 +621,27 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
                     // is), and beta P2 replaces T for the dKq product
                     const float pk = (float)(bf16)pp[k];
                     if (ok) d2v[it][k] += alpha * pk * (sv[k] > 0.f ? 1.f : 10.f);
-                    const int w = hl + 32 * k;
-                    if (ok && w < a.W) ((bf16*)a.T)[(((int64_t)j * a.Bi + i) * a.G + g) * a.Wp + w] = (bf16)(beta * pk);
+                    if constexpr (!PAIR) {
+                        const int w = hl + 32 * k;
+                        if (ok && w < a.W) ((bf16*)a.T)[(((int64_t)j * a.Bi + i) * a.G + g) * a.Wp + w] = (bf16)(beta * pk);
+                    }
+                }
+            }
+            if constexpr (PAIR) {
+                if (gram && ok) {
+#pragma unroll
+                    for (int k = 0; k < NKW; k += 2) {
+                        const int w = wslot<true>(hl, k);                // pp is zero past the last word: the pad column stays zero
+                        if (w < a.W) {
+                            const bf16 two[2] = {(bf16)(beta * (float)(bf16)pp[k]), (bf16)(beta * (float)(bf16)pp[k + 1])};
+                            *(uint32_t*)((bf16*)a.T + (((int64_t)j * a.Bi + i) * a.G + g) * a.Wp + w) = *(const uint32_t*)two;
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + hl + 32 * k] = cd[k];
+        for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + wslot<PAIR>(hl, k)] = cd[k];
     }
     if (a.stop == 3) { if (d2v[0][0] == 123.456f) rn[0] = 1.f; return; }
     __syncthreads();
@@ -624,21 +662,31 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
     bf16* S = (bf16*)a.S;
     float cc[NKW];
 #pragma unroll
-    for (int k = 0; k < NKW; ++k) { const int w = hl + 32 * k; cc[k] = w < a.W ? coldot[w] : 0.f; }
+    for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); cc[k] = w < a.W ? coldot[w] : 0.f; }
 #pragma unroll
     for (int it = 0; it < IT2; ++it) {
         const int g = 2 * wid + half + 2 * NW * it;
         if (g >= a.G) break;
         const float cr = rowdot[g];
         bf16* row = S + (((int64_t)i * a.G + g) * a.Bj + j) * a.Wp;
+        bf16 out[NKW];
 #pragma unroll
         for (int k = 0; k < NKW; ++k) {
-            const int w = hl + 32 * k;
+            const int w = wslot<PAIR>(hl, k);
+            out[k] = (bf16)0.f;
             if (w < a.W) {
                 const uint32_t u = Su[g * a.Wq + w];
                 const float sv = __uint_as_float(u & 0xffff0000u), d1r = __uint_as_float(u << 16);
                 const float ds = d1r + d2v[it][k] - sv * (cr + cc[k]);
-                row[w] = (bf16)(sv > 0.f ? ds : 0.1f * ds);
+                out[k] = (bf16)(sv > 0.f ? ds : 0.1f * ds);
+                if constexpr (!PAIR) row[w] = out[k];
+            }
+        }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int k = 0; k < NKW; k += 2) {
+                const int w = wslot<true>(hl, k);                        // a pad column next to the last word gets the zero it already holds
+                if (w < a.W) { const bf16 two[2] = {out[k], out[k + 1]}; *(uint32_t*)(row + w) = *(const uint32_t*)two; }
             }
         }
     }
