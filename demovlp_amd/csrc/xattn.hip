@@ -31,6 +31,7 @@ struct XLayout {
     int64_t Bi, Bj, G, W, Gp, Wp, es;   // es = element size
     int64_t off_chat, off_qhat, off_S, off_P1, off_P2, off_wc, off_wc2, off_st1, off_st2, off_dP1, off_dP2, off_dchat, off_dqhat,
         off_dirc, off_dirq, off_rinv, off_cinv, off_rpart, off_cpart, total;
+    int64_t off_chatp;                                   // Chat with its rows in xperm_g order (bf16 backward: dP1 comes out pair-ordered)
     int64_t off_T, off_kq, off_dkq, off_u2, off_nc;      // Gram form: P2 Kq [Bj][Bi*G][Wp], Kq / dKq [Bj][Wp][Wp], u [Bj][Bi][G] f32, |C^| [Bi][G] f32
     bool gram;
 };
@@ -59,6 +60,9 @@ static bool x_general(int64_t G, int64_t W) { return g_force_general || pair_lds
 static int g_gram = getenv("DVLP_XATTN_NO_GRAM") ? 0 : 1;
 extern "C" int dvlp_xattn_gram(int on) { g_gram = on; return DVLP_OK; }
 static int g_xbwd_packed_fwd();       // (defined below: the Gram form needs the bf16 backward kernel)
+static int g_pairg = 1;          // bf16 backward: dP1 columns in xperm_g order (A/B, tests)
+extern "C" int dvlp_xattn_pair_regions(int on) { g_pairg = on; return DVLP_OK; }
+static bool x_pairg(int dtype, int64_t G, int64_t W) { return g_pairg && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G >= 128; }
 static bool x_gram(int dtype, int64_t G, int64_t W) { return g_gram && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G <= 64 * 6; }
 
 static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd) {
@@ -68,6 +72,7 @@ static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, 
     auto take = [&](int64_t bytes) { int64_t r = o; o += rup(bytes, 256); return r; };
     L.off_chat = take(Bi * G * XD * L.es);
     L.off_qhat = take(Bj * L.Wp * XD * L.es);
+    L.off_chatp = take((bwd && x_pairg(dtype, G, W)) ? Bi * G * XD * L.es : 0);
     L.off_S = take(Bi * G * Bj * L.Wp * L.es);
     L.off_P1 = take(Bi * Bj * L.Wp * L.Gp * L.es);
     L.off_P2 = take(Bj * Bi * G * L.Wp * L.es);
@@ -128,10 +133,22 @@ template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float (&o)[
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4]) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
 template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&o)[4]) { bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3]; *(bf16x4*)p = v; }
 
+// Region order of the dP1 columns in the bf16 backward: a wave reads row w of dP1 with lane l taking regions l + 64 k.  Stored so
+// that regions g and g + 64 of every full block of 128 are NEIGHBOURS (position 2 (g % 64) + (g / 64) % 2 inside the block), slots
+// (2 k', 2 k' + 1) of a lane are one 4-byte piece instead of two 2-byte ones; regions past the last full block keep their place.
+// dP1 = d wc . Chat^T comes out in this order by itself when the product is given the rows of Chat in it (xprep writes that copy).
+__host__ __device__ __forceinline__ int xperm_g(int g, int G) {
+    const int nfull = G / 128;
+    if (g >= 128 * nfull) return g;
+    const int blk = g / 128, in = g % 128;
+    return 128 * blk + 2 * (in % 64) + in / 64;
+}
+
 // hat[row'] = raw[row] / (|raw[row]| + 1e-8); rows are remapped (r / inner) * inner_p + r % inner, pad rows zeroed
 template <typename T>
 __global__ __launch_bounds__(256) void xprep_kernel(int64_t outer, int64_t inner, int64_t inner_p, const T* __restrict__ raw, T* __restrict__ hat,
-                                                    float* __restrict__ nrm = nullptr /* |hat row| as stored (rounded to T), or null */) {
+                                                    float* __restrict__ nrm = nullptr /* |hat row| as stored (rounded to T), or null */,
+                                                    T* __restrict__ hat_perm = nullptr /* second copy, rows in xperm_g order, or null */) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= outer * inner_p) return;
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(256) void xprep_kernel(int64_t outer, int64_t inner
         for (int j = 0; j < 4; ++j) v[j] = v[j] / n;
     }
     st4<T>(hat + r * XD + lane * 4, v);
+    if (hat_perm && in < inner) st4<T>(hat_perm + (o * inner_p + xperm_g((int)in, (int)inner)) * XD + lane * 4, v);
     if (nrm) {
         float q = 0.f;
 #pragma unroll
@@ -168,6 +186,7 @@ struct PairArgs {
     float* u2;
     void* T;
     const float* ab;
+    int pairg;                    // dP1 columns are in xperm_g order
 };
 
 constexpr int XT = 1024;     // threads per pair workgroup: 16 waves share one S_ij tile (the tile caps residency at 1 block/CU)
@@ -514,9 +533,13 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
 #pragma unroll
         for (int k = 0; k < NKG; k += 2) {
             const int g0 = lane + 64 * k, g1 = g0 + 64;
-            const uint32_t lo = (w < a.W && g0 < a.G) ? D1u[(int64_t)w * a.Gp + g0] : 0u;
-            const uint32_t hi = (k + 1 < NKG && w < a.W && g1 < a.G) ? D1u[(int64_t)w * a.Gp + g1] : 0u;
-            d1p[it][k >> 1] = lo | (hi << 16);
+            if (a.pairg && 64 * (k + 2) <= a.G) {            // a full block of 128 regions: (g0, g1) are neighbours in memory (xperm_g)
+                d1p[it][k >> 1] = w < a.W ? *(const uint32_t*)(D1u + (int64_t)w * a.Gp + 64 * k + 2 * lane) : 0u;
+            } else {
+                const uint32_t lo = (w < a.W && g0 < a.G) ? D1u[(int64_t)w * a.Gp + g0] : 0u;
+                const uint32_t hi = (k + 1 < NKG && w < a.W && g1 < a.G) ? D1u[(int64_t)w * a.Gp + g1] : 0u;
+                d1p[it][k >> 1] = lo | (hi << 16);
+            }
         }
     }
     if (a.stop == 6) { if (d1p[0][0] == 0x12345678u) rn[0] = 1.f; return; }          // timing ablation: launch + dP1 rows only
@@ -1221,12 +1244,12 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
 #define DT(K, ...) do { if (dtype == DVLP_F32) hipLaunchKernelGGL(K<float>, __VA_ARGS__); else hipLaunchKernelGGL(K<bf16>, __VA_ARGS__); } while (0)
 #define TP(p) (dtype == DVLP_F32 ? (void*)(p) : (void*)(p))
     if (dtype == DVLP_F32) {
-        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (float*)chat, (float*)nullptr);
-        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (float*)qhat, (float*)nullptr);
+        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const float*)Craw, (float*)chat, (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(xprep_kernel<float>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const float*)Qraw, (float*)qhat, (float*)nullptr, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bi * G, 4)), b256, 0, st, Bi, G, G, (const bf16*)Craw, (bf16*)chat,
-                           L.gram ? (float*)(ws + L.off_nc) : (float*)nullptr);
-        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (bf16*)qhat, (float*)nullptr);
+                           L.gram ? (float*)(ws + L.off_nc) : (float*)nullptr, (bwd && x_pairg(dtype, G, W)) ? (bf16*)(ws + L.off_chatp) : (bf16*)nullptr);
+        hipLaunchKernelGGL(xprep_kernel<bf16>, dim3((unsigned)cdiv(Bj * Wp, 4)), b256, 0, st, Bj, W, Wp, (const bf16*)Qraw, (bf16*)qhat, (float*)nullptr, (bf16*)nullptr);
     }
     // S [Bi*G x Bj*Wp] = LeakyReLU(Chat [Bi*G x d] . Qhat^T): every pair at once is ONE plain product (Qhat is shared by all videos),
     // which the 256-row kernel takes (1872 tiles); as Bi batches of G = 288 rows it ran on the 128-row kernel at half the rate
@@ -1313,7 +1336,8 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
         (void)hipMemsetAsync(dirc, 0, (size_t)Bi * G * XD * 4, s2);
     }
     // dP1[i] [(Bj*Wp) x G] = dwc[i] [(Bj*Wp) x d] . Chat_i^T
-    XG(dtype, 0, 0, Bj * Wp, G, XD, wc, XD, chat, XD, dP1, Gp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * XD, G * XD,
+    const bool pairg = x_pairg(dtype, G, W);          // columns of dP1 in xperm_g order: the product takes Chat's rows in that order
+    XG(dtype, 0, 0, Bj * Wp, G, XD, wc, XD, pairg ? (void*)(ws + L.off_chatp) : chat, XD, dP1, Gp, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * XD, G * XD,
        Bj * Wp * Gp, 0, 0, stream);
     // dP2[j] [(Bi*G) x Wp] = dwc2[j] [(Bi*G) x d] . Qhat_j^T   (Gram form: formed inside the softmax backward from S_raw and T)
     if (!L.gram)
@@ -1325,6 +1349,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     pa.Bi = (int)Bi; pa.Bj = (int)Bj; pa.G = (int)G; pa.W = (int)W; pa.Gp = (int)Gp; pa.Wp = (int)Wp; pa.Wq = (int)(W | 1);
     pa.lam = lam; pa.gate = gate; pa.stop = g_xstop;
     if (L.gram) { pa.T = ws + L.off_T; pa.ab = (const float*)(ws + L.off_st2); }
+    pa.pairg = pairg ? 1 : 0;
     if (!general) {
         if (G > 64 * XMAX_NKG) return DVLP_ERR_SHAPE;
         const size_t lds = pair_lds(G, W, 1);

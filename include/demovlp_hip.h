@@ -166,6 +166,10 @@ int dvlp_xattn_bwd_variant(int packed);
    u_g = sum_w P2 S_raw and v_g = P2_g (Q^ Q^^T) P2_g^T, so the [Bj][Bi][G][d] weighted contexts are never formed (forward or backward);
    0: the weighted contexts are materialised as in the reference -- for A/B measurements and tests */
 int dvlp_xattn_gram(int on);
+/* 1 (default): bf16 backward with the per-pair LDS tile: the dP1 rows are produced with regions g and g + 64 of every full block of 128
+   adjacent (the product is handed a row-permuted copy of the unit regions), so the backward fetches them as 4-byte pieces; 0: natural
+   order -- for A/B measurements and tests */
+int dvlp_xattn_pair_regions(int on);
 /* 1: the text->image half of the local loss (its contractions and cosine passes) is issued on an internal side stream beside the
    image->text half between the softmax stages (fork / join by events, capturable); 0 (default): everything on the caller's stream */
 int dvlp_xattn_parallel_halves(int on);
