@@ -54,5 +54,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_stamp(verbose: bool = True) -> str:
+    """Developer build for tools/p8_timeline.py: the same library with gemm.hip compiled under -DDVLP_STAMP (per-workgroup
+    s_memrealtime stamps in the 256-row GEMM).  Never loaded by the product (``_lib.LIB_PATH`` points at libdemovlp_hip.so)."""
+    build(verbose=verbose)
+    hipcc = _hipcc()
+    out = os.path.join(LIBDIR, "libdemovlp_hip_stamp.so")
+    obj = os.path.join(LIBDIR, "gemm_stamp.o")
+    src = os.path.join(CSRC, "gemm.hip")
+    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "gemm.hip"] + [obj]
+    if _stale(obj, [src, os.path.join(CSRC, "common.h")]):
+        subprocess.run([hipcc, *FLAGS, "-DDVLP_STAMP", "-c", src, "-o", obj], check=True)
+    if _stale(out, objs):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_stamp() if "--stamp" in sys.argv else build(force="--force" in sys.argv))

@@ -852,6 +852,18 @@ __device__ __attribute__((noinline)) void p8_store_ragged(const Epi& e, bf16* __
     }
 }
 
+// Timeline stamps (tools/p8_timeline.py builds a second library with -DDVLP_STAMP; the product library carries none of this):
+// per workgroup {block, HW_ID, XCC_ID, entry, first data landed, K loop done, stores issued, stores acknowledged} on the 100 MHz
+// s_memrealtime clock, kept in SGPRs and written once at the very end (a store inside the K loop would count in vmcnt).
+#ifdef DVLP_STAMP
+__device__ unsigned long long* g_p8_stamp = nullptr;
+extern "C" int dvlp_p8_stamp_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_p8_stamp), &p, sizeof p) == hipSuccess ? DVLP_OK : DVLP_ERR_LAUNCH; }
+#define P8_STAMP(i) do { st[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
+struct P8Stamps { unsigned long long t[5]; };
+
 // One 256 x 256 output tile at (m0, n0) over K tiles [kbeg, kbeg + 64 nk); `slab_out` non-null: raw fp32 partial (split-K).
 // EK = epilogue kind of whole tiles: 0 bias only, 1 bias + residual, 2 GELU forward (pre-activation out), 3 GELU backward
 // (pre-activation in), 4 anything (flags read at run time).  Kinds 0-3 are straight-line code: with run-time flag tests around the
@@ -860,7 +872,7 @@ constexpr int P8_EK_ANY = 4;
 template <bool A_R, bool B_R, int EK>
 __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                         int64_t ldb, bf16* __restrict__ C, int64_t ldc, const Epi& e, int64_t m0, int64_t n0, int64_t kbeg, int nk,
-                                        float* __restrict__ slab_out) {
+                                        float* __restrict__ slab_out, unsigned long long* st = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
@@ -1015,6 +1027,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     // wait for units 0 and 1 of the prologue issued at the top
     if (nk > 1) p_vmcnt<8>(); else p_vmcnt<4>();
     __builtin_amdgcn_s_barrier();
+    P8_STAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind group 0
     for (int t = 0; t < nk; t += 2) {
         phase(I0{}, I0{}, 4 * t + 0); phase(I1{}, I0{}, 4 * t + 1); phase(I2{}, I0{}, 4 * t + 2); phase(I3{}, I0{}, 4 * t + 3);
@@ -1023,6 +1036,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                 // re-align the groups: every LDS read and DMA has retired
+    P8_STAMP(2);
 
     // Epilogue, per wave and without workgroup barriers.  The products above are issued with the B fragment as the FIRST MFMA
     // operand, so the accumulator tile is C^T: lane (g = lane / 16, r = lane % 16) holds acc[i][j][0..3] = C[row 16 i' + r][columns
@@ -1138,6 +1152,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
                                                            const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
                                                            Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef DVLP_STAMP
+    unsigned long long st[5];
+    P8_STAMP(0);
+#endif
     const int wg = xcd_remap32((int)blockIdx.x, (int)gridDim.x);
     int tm_, tn_;
     tile_of32(wg, (int)gridDim.x / (int)ntn, (int)ntn, tm_, tn_);
@@ -1146,7 +1164,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
     if (e.aux) e.aux = (bf16*)e.aux + blockIdx.y * e.sAux;
     const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
+#ifdef DVLP_STAMP
+    p8_tile<A_R, B_R, EK>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out, st);
+    P8_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_STAMP(4);
+    if (g_p8_stamp && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = g_p8_stamp + 8 * (size_t)blockIdx.x;
+        o[0] = blockIdx.x; o[1] = hw; o[2] = xcc;
+        for (int i = 0; i < 5; ++i) o[3 + i] = st[i];
+    }
+#else
     p8_tile<A_R, B_R, EK>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
+#endif
 }
 
 // Grouped weight gradients: up to P8G_MAX independent dW_p = dY_p^T X_p products (all form R x form R, fp32 out) in ONE

@@ -107,6 +107,10 @@ class RegionBatcher:
     def __init__(self, batch: int, frames: int, regions: int, max_regions: int = 100, device: str | torch.device = "cuda", nbuf: int = 2):
         self.B, self.F, self.R, self.M = batch, frames, regions, max_regions
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None and torch.cuda.is_available():
+            # resolve to an INDEXED device now, on the constructing thread: a worker thread (prefetching()) starts with torch's
+            # current device 0 whatever set_device(LOCAL_RANK) the main thread did
+            self.device = torch.device("cuda", torch.cuda.current_device())
         pin = self.device.type == "cuda"
         self.bufs = [_Staging(batch, frames, max_regions, pin) for _ in range(max(1, nbuf))]
         self.cur = 0
@@ -156,6 +160,8 @@ class RegionBatcher:
         if self.device.type != "cuda":
             raise ops._lib.DemoVLPHipError("RegionBatcher.to_device needs a ROCm device: there is no CPU fallback")
         s = self.bufs[self.cur]
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)                  # worker threads start on device 0 (see __init__)
         cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.copy_stream):
             d = [t.to(self.device, non_blocking=True) for t in s.tensors()]
@@ -170,17 +176,29 @@ class RegionBatcher:
         return obj, mask, lens
 
 
-def prefetching(batches: Iterable, depth: int = 2) -> Iterator:
+def prefetching(batches: Iterable, depth: int = 2, device=None) -> Iterator:
     """Run a batch iterator (file reads + staging + enqueueing of copies) on a background thread, ``depth`` batches ahead of the
     consumer: host file I/O for batch k+1 overlaps the device step of batch k (the reference gets this from DataLoader workers,
-    base/base_data_loader.py:23-38)."""
+    base/base_data_loader.py:23-38).
+
+    The worker thread adopts the CALLER's current device (or ``device``): a fresh thread starts on device 0 regardless of the
+    ``torch.cuda.set_device(LOCAL_RANK)`` the main thread did.  The worker allocates, copies and launches, so it must not run while
+    a hipGraph is being captured in 'global' error mode (``GraphedTrainStep`` captures on its third call): start it after the
+    capturing step, or capture with ``capture_error_mode='thread_local'``."""
     import queue
     import threading
     q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
     END = object()
+    dev = None
+    if torch.cuda.is_available():
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.type != "cuda":
+            dev = None
 
     def run():
         try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
             for b in batches:
                 q.put(b)
             q.put(END)

@@ -180,6 +180,13 @@ class FusedAdamW:
         self._early = []
         Fn.EARLY_OPT = self._early_update
 
+    def abort_overlapped(self):
+        """Drop an overlapped step that did not reach launch() (forward / backward raised): clears the per-layer hook and the record
+        of early updates so the next zero_grad() / step starts clean.  Layers already updated stay updated (their moments too)."""
+        if Fn.EARLY_OPT is not None and getattr(Fn.EARLY_OPT, "__self__", None) is self:
+            Fn.EARLY_OPT = None
+        self._early = None
+
     def _early_update(self, params):
         a = self.arena
         idx = sorted(self._index_of[id(q)] for q in params)
@@ -461,8 +468,13 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
         reducer.begin()
     elif isinstance(optimizer, FusedAdamW) and not (dist.is_initialized() and dist.get_world_size() > 1):
         optimizer.begin_overlapped()           # no gradient exchange: the layers' updates ride along with the backward
-    losses = forward_backward(model, loss_fn, data, gather_negatives)
-    scale = reducer.finish() if reducer is not None else 1.0
+    try:
+        losses = forward_backward(model, loss_fn, data, gather_negatives)
+        scale = reducer.finish() if reducer is not None else 1.0
+    except BaseException:
+        if isinstance(optimizer, FusedAdamW):
+            optimizer.abort_overlapped()         # a bad batch must not wedge the optimizer ("begin_overlapped() without ...")
+        raise
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(grad_scale=scale)
     else:
@@ -561,8 +573,13 @@ class GraphedTrainStep:
         if not self.collective:
             self.opt.begin_overlapped()
         self._set_cut()
-        losses = backward_first(self.model, self.loss_fn, data)
-        self._set_cut(False)
+        try:
+            losses = backward_first(self.model, self.loss_fn, data)
+        except BaseException:
+            self.opt.abort_overlapped()
+            raise
+        finally:
+            self._set_cut(False)
         handles = []
         if self.cut is not None:
             self.opt._adopt_stray_grads()
@@ -618,10 +635,14 @@ class GraphedTrainStep:
                 self.static["text"][k].copy_(v, non_blocking=True)
             self.static["object"].copy_(data["object"], non_blocking=True)
             self.static["object_mask"].copy_(data["object_mask"], non_blocking=True)
+        if not self.collective:
+            # the captured AdamW kernels read lr / betas / eps / wd / the step counter from the device buffer: follow any change the
+            # host made since the last call (param_groups[0]['lr'] = ..., load_state_dict) -- outside the graph, copies only on change
+            self.opt._sync_hyper(1.0)
         self.graph.replay()
         if not self.collective:
             self.opt.replayed()
-            return self.out
+            return tuple(t.clone() for t in self.out)          # fresh tensors, like the eager step: a later replay must not rewrite them
         handles = []
         if self.graph2 is not None:
             handles = self._exchange(self.early_runs, overlapped=True)     # travels while the second graph runs
@@ -630,7 +651,7 @@ class GraphedTrainStep:
         for h in handles:
             h.wait()
         self.opt.launch(grad_scale=1.0 / self.world)
-        return self.out
+        return tuple(t.clone() for t in self.out)
 
 
 def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False, log=None):

@@ -365,8 +365,8 @@ def test_region_batcher_back_to_back_batches(tmp_path):
             assert list(lens[b].cpu().numpy()) == rl
 
 
-@pytest.mark.parametrize("graph", [1, 0])
-def test_bench_rccl_path_in_a_one_rank_group(graph):
+@pytest.mark.parametrize("graph,gather", [(1, False), (0, False), (0, True)], ids=["graph", "eager", "eager-gather-negatives"])
+def test_bench_rccl_path_in_a_one_rank_group(graph, gather):
     """bench.py over the real `nccl` (= RCCL) backend with world_size 1: process-group init on the device, the gradient
     all-reduce of every arena bucket (hook-driven GradReducer when --graph 0, post-graph bucketed all-reduce when --graph 1),
     barrier + max-over-ranks timing, and the JSON contract."""
@@ -375,7 +375,7 @@ def test_bench_rccl_path_in_a_one_rank_group(graph):
     env = dict(os.environ, DVLP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
-           "--graph", str(graph)]
+           "--graph", str(graph)] + (["--gather-negatives"] if gather else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:                   # one retry on a fresh port: process-group bring-up on a cold box is the only part not under our control
         print("first attempt failed:", r.stderr[-3000:])
@@ -389,6 +389,8 @@ def test_bench_rccl_path_in_a_one_rank_group(graph):
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
     assert out["roofline"]["object_transformer_frac"] > 0
     assert np.isfinite(out["config"]["final_loss"])
+    # --gather-negatives: AllGather_multi over RCCL on device tensors (a one-rank gather is the identity, so the loss is unchanged)
+    assert out["config"]["negatives"] == ("all-gathered" if gather else "per-rank (reference default)")
     # the two exchange schemes (and the plain single-GPU step) train the same model: compare against a run without a process group
     env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DVLP_FORCE_DIST")}
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
