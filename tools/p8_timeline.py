@@ -30,11 +30,16 @@ lib.dvlp_p8_stamp_buffer.restype = ctypes.c_int
 dev = "cuda"
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)  # noqa: E731
 g = torch.Generator(device=dev).manual_seed(0)
-M = 18496
+M0 = 18496
+lib.dvlp_gemm_p8_mode(2)                    # also for grids the dispatch would give to the 128-row kernel
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-shapes = [("qkv fwd (bias)", 2304, 768, 0, 0, "b"), ("proj fwd (bias+res)", 768, 768, 0, 0, "br"), ("fc1 fwd (gelu, aux out)", 3072, 768, 0, 1, "ba"),
-          ("fc2 dX (gelu', aux in)", 3072, 768, 1, 2, "a"), ("fc2 fwd (bias+res) K=3072", 768, 3072, 0, 0, "br")]
-for label, N, K, tb, flags, ops_ in shapes:
+shapes = [("qkv fwd (bias)", M0, 2304, 768, 0, 0, "b"), ("proj fwd (bias+res)", M0, 768, 768, 0, 0, "br"), ("fc1 fwd (gelu, aux out)", M0, 3072, 768, 0, 1, "ba"),
+          ("fc2 dX (gelu', aux in)", M0, 3072, 768, 1, 2, "a"), ("fc2 fwd (bias+res) K=3072", M0, 768, 3072, 0, 0, "br"),
+          # is the 5-10 us epilogue a per-CU limit or the chip's store rate?  the same tiles on a quarter / half of the CUs
+          ("fc1 fwd on 60 CUs", 5 * 256, 3072, 768, 0, 1, "ba"), ("fc1 fwd on 132 CUs", 11 * 256, 3072, 768, 0, 1, "ba"), ("fc1 fwd on 252 CUs", 21 * 256, 3072, 768, 0, 1, "ba")]
+if len(sys.argv) > 1:
+    shapes = [s_ for s_ in shapes if any(k in s_[0] for k in sys.argv[1:])]
+for label, M, N, K, tb, flags, ops_ in shapes:
     A = torch.randn(M, K, device=dev, generator=g).bfloat16()
     B = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() if not tb else (torch.randn(K, N, device=dev, generator=g) * 0.02).bfloat16()
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
@@ -64,7 +69,9 @@ for label, N, K, tb, flags, ops_ in shapes:
     torch.cuda.synchronize()
     lib.dvlp_p8_stamp_buffer(ctypes.c_void_p(0))
     r = buf.cpu().numpy().reshape(ntile, 8)
-    assert (r[:, 0] == np.arange(ntile)).all(), "some workgroups left no stamp"
+    if not (r[:, 0] == np.arange(ntile)).all():
+        print(f"\n=== {label}: not run on the 256-row kernel (no stamps) -- skipped")
+        continue
     t = (r[:, 3:8] - r[:, 3].min()) * 0.01                     # us
     cu = ((r[:, 2] & 0xF) << 8) | ((r[:, 1] >> 8) & 0xFF)      # (xcc, se, sh, cu)
     ncu = len(np.unique(cu))
