@@ -869,7 +869,12 @@ struct P8Stamps { unsigned long long t[5]; };
 // (pre-activation in), 4 anything (flags read at run time).  Kinds 0-3 are straight-line code: with run-time flag tests around the
 // residual / aux loads the compiler closes every step with s_waitcnt vmcnt(0), which also waits for the previous step's stores.
 constexpr int P8_EK_ANY = 4;
-template <bool A_R, bool B_R, int EK>
+// MIH: 16-row blocks per wave in the UPPER half of the tile (rows 128..): 4 = 256-row tile; 3 = 224-row tile (the upper unit is still
+// staged whole, its last 32 rows are simply not multiplied).  Tile height is a ROUND-QUANTISATION knob: with M = 18496 tokens, 256-row
+// tiles give 73 x {3, 9, 12} = 219 / 657 / 876 tiles = 1 / 3 / 4 rounds on 256 CUs for 0.86 / 2.57 / 3.42 rounds of work, 224-row tiles
+// give 83 x {3, 9, 12} = 249 / 747 / 996 tiles: the same 1 / 3 / 4 rounds, each 7/8 as long.
+template <int MIH> constexpr int p8_tile_rows() { return 128 + 32 * MIH; }
+template <bool A_R, bool B_R, int EK, int MIH = 4>
 __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                         int64_t ldb, bf16* __restrict__ C, int64_t ldc, const Epi& e, int64_t m0, int64_t n0, int64_t kbeg, int nk,
                                         float* __restrict__ slab_out, unsigned long long* st = nullptr) {
@@ -877,6 +882,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int U = 4 * nk;
+    static_assert(MIH == 4 || !A_R, "short tiles are only built for row-major (form K) A operands");
 
     // per-lane source pointers of this wave's two LDS-DMA pieces of every unit kind; they advance one K tile per use
     auto src_ptr = [&](auto form_r, const bf16* X, int64_t ld, int64_t r0, int64_t R, int j) -> const bf16* {
@@ -927,10 +933,11 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
 
     // per-lane fragment-read offsets inside a unit
     const int g = lane >> 4, r = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
-    unsigned aK[2], bK[2], aR[4], bR[2];
+    unsigned aK[2], aKh[2], bK[2], aR[4], bR[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         aK[s] = (unsigned)((64 * wr + r) * 128 + (((4 * s + g) ^ (r & 7)) << 4));
+        aKh[s] = (unsigned)((16 * MIH * wr + r) * 128 + (((4 * s + g) ^ (r & 7)) << 4));      // upper half: MIH blocks per wave group
         bK[s] = (unsigned)((32 * wc + r) * 128 + (((4 * s + g) ^ (r & 7)) << 4));
     }
 #pragma unroll
@@ -962,7 +969,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) aF[s][i] = *(const bf16x8*)(smem_raw + PAR * P_BUF + KOFF + aK[s] + i * 2048);
+                for (int i = 0; i < (KOFF ? MIH : 4); ++i) aF[s][i] = *(const bf16x8*)(smem_raw + PAR * P_BUF + KOFF + (KOFF ? aKh : aK)[s] + i * 2048);
         }
     };
     auto read_b = [&](auto par_, auto kind_, bf16x8 (&bf)[2][2], bf16x4 (&lo)[2][2], bf16x4 (&hi)[2][2]) {
@@ -1016,7 +1023,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < (MI ? MIH : 4); ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((NJ ? bH : bL)[s][j], aF[s][i], acc[MI + i][NJ + j], 0, 0, 0);
@@ -1047,7 +1054,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     if (ab & 16) { if (acc[0][0][0] == 123.456f && acc[7][3][3] == 1.f) C[0] = (bf16)1.f; return; }
     if (ab & 8) M = 0;
     const int r16 = lane & 15, g4 = lane >> 4;
-    auto row_of = [&](int ii) { return m0 + 128 * (ii >> 2) + 64 * wr + 16 * (ii & 3) + r16; };
+    auto row_of = [&](int ii) { return m0 + (ii < 4 ? 64 * wr : 128 + 16 * MIH * wr) + 16 * (ii & 3) + r16; };
     if (slab_out && n0 + 256 <= N && (N & 3) == 0) {
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii) {
@@ -1090,8 +1097,8 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         };
         preload(0, pr[0], pa[0]); preload(1, pr[1], pa[1]); preload(2, pr[2], pa[2]);
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
-            if (ii < 5) preload(ii + 3, pr[(ii + 3) & 3], pa[(ii + 3) & 3]);
+        for (int ii = 0; ii < 4 + MIH; ++ii) {
+            if (ii + 3 < 4 + MIH) preload(ii + 3, pr[(ii + 3) & 3], pa[(ii + 3) & 3]);
             const int64_t m = row_of(ii);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -1117,7 +1124,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
 #pragma unroll
                 for (int t = 0; t < 8; ++t) cs[hh][t] = row16_sum(cs[hh][t]);
                 if (r16 == 0) {
-                    float* dst = e.csum + ((m0 >> 8) * 2 + wr) * N + cn0 + 128 * hh;
+                    float* dst = e.csum + ((m0 / p8_tile_rows<MIH>()) * 2 + wr) * N + cn0 + 128 * hh;
                     *(float4*)dst = make_float4(cs[hh][0], cs[hh][1], cs[hh][2], cs[hh][3]);
                     *(float4*)(dst + 4) = make_float4(cs[hh][4], cs[hh][5], cs[hh][6], cs[hh][7]);
                 }
@@ -1125,6 +1132,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
         return;
     }
+    if constexpr (MIH != 4) return;      // short tiles are only dispatched when every tile takes the path above
     // ragged tiles / unaligned outputs: four 32-row passes through LDS (rows {lo, hi} x {first, second 32}; a pass covers the
     // wave's 32 + 32 columns), scalar epilogue out of line
     constexpr int P_EPW = 32 * 68 * 4;                         // bytes per wave: staged accumulators
@@ -1147,7 +1155,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
 }
 constexpr int P_EPI_LDS = 8 * (32 * 68 * 4);
 
-template <bool A_R, bool B_R, int EK>
+template <bool A_R, bool B_R, int EK, int MIH = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
                                                            const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
                                                            Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
@@ -1165,7 +1173,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
     const int64_t kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     float* slab_out = slab ? slab + (int64_t)(blockIdx.y * gridDim.z + blockIdx.z) * M * N : nullptr;
 #ifdef DVLP_STAMP
-    p8_tile<A_R, B_R, EK>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out, st);
+    p8_tile<A_R, B_R, EK, MIH>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * p8_tile_rows<MIH>(), (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out, st);
     P8_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P8_STAMP(4);
@@ -1178,7 +1186,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
         for (int i = 0; i < 5; ++i) o[3 + i] = st[i];
     }
 #else
-    p8_tile<A_R, B_R, EK>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * 256, (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
+    p8_tile<A_R, B_R, EK, MIH>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * p8_tile_rows<MIH>(), (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
 #endif
 }
 
@@ -1294,6 +1302,8 @@ static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile pat
 extern "C" int dvlp_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
 extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
+static int g_p8_short = 1;       // 224-row tiles of the 256-row kernel: 0 never, 1 where they save CU-rounds (default), 2 whenever allowed
+extern "C" int dvlp_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
 static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
 extern "C" int dvlp_gemm_force_split(int s) { g_force_split = s; return DVLP_OK; }
 static int g_wgrad_split = 0;    // grouped weight gradients: 0 = automatic uniform K split, > 0 = forced
@@ -1455,22 +1465,19 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;
         S = cdiv(K, kchunk);
         float* slab = S > 1 ? g_ws : nullptr;
-        if (csum_dst && p8 && batch == 1 && S == 1 && e.vec && N % 256 == 0 && !(flags & EPI_OUT_F32)) {
-            e.csum = dvlp_rd_reserve_push(2 * ntm8, N, csum_dst);      // partial rows: (row tile, upper / lower wave group)
-            csum_fused = e.csum != nullptr;
-        }
         dim3 grid((unsigned)(ntm * ntn), (unsigned)batch, (unsigned)S), block(256);
         // > 64 KiB of dynamic LDS must be opted into once per kernel
 #define LAUNCH_BF16_(AR, BR, SF) do { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AR, BR, SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); } \
         hipLaunchKernelGGL((gemm_bf16_kernel<AR, BR, SF>), grid, block, lds, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn, kchunk, slab); } while (0)
-#define LAUNCH_P8K_(AR, BR, EK) do { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AR, BR, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
-        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR, EK>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
+#define LAUNCH_P8K_(AR, BR, EK, MIH) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AR, BR, EK, MIH>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR, EK, MIH>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn8, kchunk, slab); } while (0)
-#define LAUNCH_P8_(AR, BR) do { if (ek8 == 0) LAUNCH_P8K_(AR, BR, 0); else if (ek8 == 1) LAUNCH_P8K_(AR, BR, 1); else if (ek8 == 2) LAUNCH_P8K_(AR, BR, 2); \
-        else if (ek8 == 3) LAUNCH_P8K_(AR, BR, 3); else LAUNCH_P8K_(AR, BR, P8_EK_ANY); } while (0)
+#define LAUNCH_P8S_(AR, BR, EK) do { if constexpr (!AR) { if (mih8 == 3) { LAUNCH_P8K_(AR, BR, EK, 3); break; } } LAUNCH_P8K_(AR, BR, EK, 4); } while (0)
+#define LAUNCH_P8_(AR, BR) do { if (ek8 == 0) LAUNCH_P8S_(AR, BR, 0); else if (ek8 == 1) LAUNCH_P8S_(AR, BR, 1); else if (ek8 == 2) LAUNCH_P8S_(AR, BR, 2); \
+        else if (ek8 == 3) LAUNCH_P8S_(AR, BR, 3); else LAUNCH_P8K_(AR, BR, P8_EK_ANY, 4); } while (0)
 #define LAUNCH_GLDS_(AR, BR) do { if (p8) LAUNCH_P8_(AR, BR); else if (wide) { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128); } \
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4, 3>), gridw, dim3(512), (size_t)3 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
@@ -1482,10 +1489,24 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         const int64_t ntm_w = cdiv(M, 256);
         const bool wide = dma && !p8 && g_wide_mode != 0 && (g_wide_mode == 2 || ntm_w * ntn * batch * S >= 512);
         dim3 gridw((unsigned)(ntm_w * ntn), (unsigned)batch, (unsigned)S);
-        dim3 grid8((unsigned)(ntm8 * ntn8), (unsigned)batch, (unsigned)S);
         // epilogue kind of the 256-row kernel (see p8_tile)
         const int fmask8 = flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD | EPI_ACCUM | EPI_OUT_F32);
         const int ek8 = g_ablate ? P8_EK_ANY : fmask8 == 0 ? (res ? 1 : 0) : (fmask8 == EPI_GELU && !res) ? 2 : (fmask8 == EPI_GELU_BWD && !res) ? 3 : P8_EK_ANY;
+        // tile height (p8_tile_rows): 224-row tiles when they need fewer CU-rounds x rows than 256-row ones (M = 18496: 83 x {3, 9, 12}
+        // = 249 / 747 / 996 tiles fill 1 / 3 / 4 rounds of 256 CUs that 219 / 657 / 876 tiles of 256 rows leave 14 % empty).  Only where
+        // every tile takes the whole-tile epilogue: row-major A, whole 256-column tiles, aligned outputs, no K split.
+        static const int ncu8 = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+        int mih8 = 4;
+        if (p8 && g_p8_short != 0 && !transA && S == 1 && batch == 1 && N % 256 == 0 && e.vec && ek8 != P8_EK_ANY) {
+            const int64_t t224 = cdiv(M, 224) * ntn8;
+            if (g_p8_short == 2 || cdiv(t224, ncu8) * 224 < cdiv(tiles8, ncu8) * 256) mih8 = 3;
+        }
+        const int64_t ntm8h = mih8 == 3 ? cdiv(M, 224) : ntm8;
+        if (csum_dst && p8 && batch == 1 && S == 1 && e.vec && N % 256 == 0 && !(flags & EPI_OUT_F32)) {
+            e.csum = dvlp_rd_reserve_push(2 * ntm8h, N, csum_dst);     // partial rows: (row tile, upper / lower wave group)
+            csum_fused = e.csum != nullptr;
+        }
+        dim3 grid8((unsigned)(ntm8h * ntn8), (unsigned)batch, (unsigned)S);
 #define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         rec.kern = p8 ? 2 : dma ? 1 : 0;
         if (!transA && !transB) LAUNCH_BF16(false, false);
@@ -1498,6 +1519,8 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
 #undef LAUNCH_BF16_
 #undef LAUNCH_GLDS_
 #undef LAUNCH_P8_
+#undef LAUNCH_P8S_
+#undef LAUNCH_P8K_
 #undef LAUNCH_BF16
     } else {
         return DVLP_ERR_DTYPE;

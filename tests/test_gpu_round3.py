@@ -335,3 +335,42 @@ def test_bf16_ten_step_loss_curve_through_graph_replay_vs_f64_curve(tag, lr):
     assert stepper.graph is not None
     assert dev.max() < BF16_CURVE_TOL[tag], dev.max(axis=1)
     assert curve[-1, 0] < curve[0, 0] - 2.0                              # and it trains
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 224-row tiles of the 256-row GEMM kernel (round quantisation): the same arithmetic per output element, so bit-equal results
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(18496, 2304, 768), (18496, 768, 3072), (2000, 768, 768), (225, 256, 128), (6400, 3072, 768)])
+def test_gemm_short_tiles_bit_equal_to_256_row_tiles(M, N, K):
+    """dvlp_gemm_p8_short_tiles: every epilogue kind of the forward / dX products (bias, +residual, GELU with pre-activation out,
+    GELU' with pre-activation in and fused column sums) on 224-row tiles against 256-row tiles: identical bits, ragged last row
+    tile included (18496 = 82 x 224 + 128; 2000 = 8 x 224 + 208; 225 = 224 + 1)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, device=DEV, generator=g).to(bf)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(bf)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(bf)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(bf)
+    pre = torch.randn(M, K, device=DEV, generator=g).to(bf)
+    ops.call("dvlp_gemm_p8_mode", 2)
+    ops.enable_deferred_reductions(torch.device(DEV), workspace_mb=64)
+    try:
+        outs = []
+        for mode in (0, 2):
+            ops.call("dvlp_gemm_p8_short_tiles", mode)
+            aux = torch.empty(M, N, device=DEV, dtype=bf)
+            cs = torch.zeros(K, device=DEV)
+            o = [ops.linear_fwd(x, w, bias), ops.linear_fwd(x, w, bias, res=res), ops.linear_fwd(x, w, bias, gelu_aux=aux), aux,
+                 ops.linear_bwd_input(dy, w), ops.linear_bwd_input(dy, w, gelu_pre=pre, colsum_to=cs)]
+            ops.flush_reductions()
+            outs.append([t.clone() for t in o] + [cs.clone()])
+        for a, b in zip(outs[0][:-1], outs[1][:-1]):
+            assert torch.equal(a, b)
+        assert torch.allclose(outs[0][-1], outs[1][-1], rtol=1e-5, atol=1e-4)      # partial sums grouped by row tile: fp32 rounding only
+        ref = x.float() @ w.float().t() + bias
+        assert float((outs[1][0].float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    finally:
+        ops.disable_deferred_reductions()
+        ops.call("dvlp_gemm_p8_short_tiles", 1)
+        ops.call("dvlp_gemm_p8_mode", 1)
