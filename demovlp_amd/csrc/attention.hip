@@ -38,6 +38,14 @@ struct AttnArgs {
     const uint8_t *keep, *keepT;
     float kscale;
     int Ns;
+    // space mode, bf16, CLS query folded into the frame waves (round 3): the CLS query rides along as query row R of every frame
+    // tile in the FORWARD too -- each wave leaves the CLS row's softmax over its own keys (normalised output [64] + (max, sum)) in
+    // `cls_o` / `cls_st`, attn_fwd_cls_combine_kernel merges the F partials flash-style and keeps the global (max, sum) in
+    // `cls_stats` [B, H, 4]; the backward reads them back (no statistics pass), takes D = <dO_cls, O_cls> from the forward output
+    // `fwd_out`, and leaves per-frame partials of dq_cls in `dq_ws` for the closing launch.
+    float *cls_o, *cls_st, *cls_stats, *dq_ws;
+    const void* fwd_out;
+    int64_t ld_fo;
 };
 static thread_local const uint8_t *t_keep = nullptr, *t_keepT = nullptr;
 static thread_local float t_kscale = 1.f;
@@ -520,6 +528,10 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
     int h, b;
     if (a.mode == 0) { sg.f = item % a.F; h = (item / a.F) % a.H; b = item / (a.F * a.H); }
     else { sg.qbase = (item % qgroups) * 16 * NQT; h = (item / qgroups) % a.H; b = item / (qgroups * a.H); }
+    const bool fold = a.mode == 0 && a.cls_o != nullptr;        // wave-uniform: the CLS query is query row R of this frame's tile
+    const int cq = a.R >> 4, cc = a.R & 15;                      // its tile and column in the S^T layout
+    const Seg sge = sg;                                          // rows emitted to `out`: the frame's regions only
+    sg.cls_q = fold ? 1 : 0;
     const int64_t brow0 = (int64_t)b * a.N;
     const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; bf16* out = (bf16*)a.out;
     bf16* Vs = (bf16*)smraw + wid * (NKTP * 16 * VLD);
@@ -552,7 +564,12 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r]; m = fmaxf(m, st[kt][qt][r]); }
+            for (int r = 0; r < 4; ++r) {
+                st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r];
+                // CLS query x CLS key belongs to frame 0's partial only
+                if (kt == 0 && r == 0 && fold && qt == cq && c == cc && g == 0 && sg.f != 0) st[kt][qt][r] = -INFINITY;
+                m = fmaxf(m, st[kt][qt][r]);
+            }
         m = col4_max(m);
         float sum = 0.f;
 #pragma unroll
@@ -560,6 +577,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
         sum = col4_sum(sum);
+        if (fold && qt == cq && c == cc && g == 0) { a.cls_st[2 * (int64_t)item] = m; a.cls_st[2 * (int64_t)item + 1] = sum; }
         const float inv = 1.f / sum;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -597,7 +615,32 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, i
             for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[qt], vb, o[qt][dt], 0, 0, 0);
         }
     }
-    emit_rows<NQT>(Vs, o, 1.f, out, brow0, a.ldo, h, sg, false, lane);
+    if (fold) {          // the CLS row's partial (normalised over this frame's keys) stays fp32: merged by attn_fwd_cls_combine_kernel
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * qt + 4 * g + r == a.R) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) a.cls_o[(int64_t)item * HD + 16 * dt + c] = o[qt][dt][r];
+                }
+    }
+    emit_rows<NQT>(Vs, o, 1.f, out, brow0, a.ldo, h, sge, false, lane);
+}
+
+// CLS query, forward: merge the F per-frame partials of one (b, h) -- out = sum_f w_f o_f, w_f = l_f e^(m_f - M) / L -- and keep the
+// global softmax statistics (M, L) for the backward
+__global__ __launch_bounds__(64) void attn_fwd_cls_combine_kernel(AttnArgs a) {
+    const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+    const int64_t bh = (int64_t)b * a.H + h;
+    const float* st = a.cls_st + bh * a.F * 2;
+    const float* o = a.cls_o + bh * a.F * HD;
+    float M = -INFINITY;
+    for (int f = 0; f < a.F; ++f) M = fmaxf(M, st[2 * f]);
+    float L = 0.f, acc = 0.f;
+    for (int f = 0; f < a.F; ++f) { const float w = st[2 * f + 1] * __expf(st[2 * f] - M); L += w; acc += w * o[f * HD + lane]; }
+    ((bf16*)a.out)[(int64_t)b * a.N * a.ldo + h * HD + lane] = (bf16)(acc / L);
+    if (lane == 0) { float* s4 = a.cls_stats + bh * 4; s4[0] = M; s4[1] = L; s4[2] = 0.f; s4[3] = 0.f; }
 }
 
 // backward, space mode: one wave per (b, h, frame).  Layout 1 (S^T) -> dQ; layout 2 (S) -> dK, dV.  P is recomputed.
@@ -800,7 +843,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     bf16* Ts = (bf16*)smraw + wid * (TROWS * VLD);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const float* st3 = stats + ((int64_t)b * a.H + h) * 4;
-    const float m_cls = st3[0], il_cls = 1.f / st3[1], D_cls = st3[2];
+    const float m_cls = st3[0], il_cls = 1.f / st3[1];
+    float D_cls = st3[2];
+    if (a.fwd_out) {     // statistics saved by the forward: D = sum_j p_j <dO_cls, v_j> = <dO_cls, O_cls>
+        const float pd = (float)((const bf16*)a.fwd_out)[brow0 * a.ld_fo + h * HD + lane] * (float)dout[brow0 * a.ldo + h * HD + lane];
+        D_cls = wave_sum(pd);
+    }
 
     bf16x8 qf[NT][2], gf[NT][2], kf[NT][2], vf[NT][2];
     load_row_frags<NT>(qf, q, brow0, a.ld, h, sg, false, lane);
@@ -922,6 +970,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, kb[ks][dt], dqa[qt][dt], 0, 0, 0);
         }
+    if (a.dq_ws) {       // dq of the CLS query: this frame's share (summed by attn_bwd_cls_post_kernel)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * qt + 4 * g + r == a.R) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) a.dq_ws[(int64_t)item * HD + 16 * dt + c] = dqa[qt][dt][r] * a.scale;
+                }
+    }
     emit_rows<NT>(Ts, dqa, a.scale, dq, brow0, a.ldd, h, sgp, false, lane);
 }
 
@@ -1011,6 +1069,12 @@ __global__ __launch_bounds__(64) void attn_bwd_cls_post_kernel(AttnArgs a) {
     const int64_t off = (int64_t)b * a.N * a.ldd + h * HD + lane;
     ((T*)a.dk)[off] = from_f<T>(gk);
     ((T*)a.dv)[off] = from_f<T>(gv);
+    if (a.dq_ws) {
+        const float* wq = a.dq_ws + (((int64_t)b * a.H + h) * a.F) * HD;
+        float gq = 0.f;
+        for (int f = 0; f < a.F; ++f) gq += wq[f * HD + lane];
+        ((T*)a.dq)[off] = from_f<T>(gq);
+    }
 }
 
 // backward, full (text) mode: one workgroup per (b, h); K, Q and dO tiles are staged once in LDS and shared; wave w owns
@@ -1213,8 +1277,15 @@ static int attn_check(const AttnArgs& a) {
     return DVLP_OK;
 }
 
+static int g_attn_fold = 1;        // space-mode bf16: 1 = CLS query folded into the frame waves when the caller passes workspaces, 0 = separate launches (A/B, tests)
+extern "C" int dvlp_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
+
+// `workspace` (B*H*F*66 floats) + `cls_stats` (B*H*4 floats), both optional: space mode, bf16 -- the CLS query is folded into the
+// frame waves and its global softmax statistics are kept in `cls_stats` for dvlp_attention_bwd.  `cls_stats[0]` is set to NaN when
+// the fold did not apply (the backward then runs its own statistics pass).
 extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
-                                  const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, void* stream) {
+                                  const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
+                                  float* cls_stats, void* stream) {
     dvlp_clear_status();
     AttnArgs a{};
     a.abl = g_attn_abl;
@@ -1241,12 +1312,17 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
             hipLaunchKernelGGL((mattn_fwd_kernel<NQT_, NKT_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_, (int)(QG)); done = true; } while (0)
         if (mode == 0) {
             const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
+            // fold: the CLS row needs a free query slot in the frame tile (R + 1 <= 16 nqt)
+            if (workspace && cls_stats && g_attn_fold && nqt == nkt && nqt <= 3) {
+                a.cls_o = workspace; a.cls_st = workspace + B * H * F * HD; a.cls_stats = cls_stats;
+            }
             if (nqt == 3 && nkt == 3) MFWD(3, 3, B * H * F, 1);
             else if (nqt == 2 && nkt == 2) MFWD(2, 2, B * H * F, 1);
             else if (nqt == 1 && nkt == 1) MFWD(1, 1, B * H * F, 1);
             else if (nqt == 1 && nkt == 2) MFWD(1, 2, B * H * F, 1);
             else if (nqt == 2 && nkt == 3) MFWD(2, 3, B * H * F, 1);
-            if (done) {   // CLS query
+            if (done && a.cls_o) hipLaunchKernelGGL(attn_fwd_cls_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(64), 0, st, a);
+            else if (done) {   // CLS query on the streaming VALU workgroup
                 AttnArgs c = a; c.seg_begin = nseg;
                 hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(1, (unsigned)H, (unsigned)B), block, lds, st, c);
             }
@@ -1262,10 +1338,12 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
     return dvlp_launch_status();
 }
 
-// workspace (space mode only): fp32 [B*H*F*2*64]
+// workspace (space mode only): fp32 [B*H*(F*3*64 + 4)]; `fwd_out` / `cls_stats`: the forward's output and the CLS statistics it saved
+// (dvlp_attention_fwd with workspaces), both optional
 extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
                                   const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk,
-                                  void* dv, int64_t ldd, float* workspace, float scale, void* stream) {
+                                  void* dv, int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out,
+                                  const float* cls_stats, void* stream) {
     dvlp_clear_status();
     AttnArgs a{};
     a.abl = g_attn_abl;
@@ -1295,7 +1373,10 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
         if (mode == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0 && R + 1 <= 48 && g_attn_merged) {
             const int nt = (int)cdiv(R + 1, 16), items = (int)(B * H * F);
             float* stats = workspace + B * H * F * 2 * HD;
-            hipLaunchKernelGGL(attn_bwd_cls_pre_kernel<bf16>, grid2, block, lds2, st, a, stats);
+            if (fwd_out && cls_stats && g_attn_fold) {      // statistics from the folded forward: no statistics pass, dq_cls from per-frame partials
+                stats = const_cast<float*>(cls_stats);
+                a.fwd_out = fwd_out; a.ld_fo = ld_fwd_out; a.dq_ws = workspace + B * H * F * 2 * HD + B * H * 4;
+            } else hipLaunchKernelGGL(attn_bwd_cls_pre_kernel<bf16>, grid2, block, lds2, st, a, stats);
 #define MMRG(NT_) hipLaunchKernelGGL((mattn_bwd_space_merged_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, \
                                      (size_t)4 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16), st, a, items, (const float*)stats)
             if (nt == 3) MMRG(3); else if (nt == 2) MMRG(2); else MMRG(1);

@@ -289,43 +289,52 @@ class VitBlockFn(torch.autograd.Function):
     """SpaceTimeBlock with time_module falsy (model/object_transformer.py:249-274): pre-LN space attention + MLP."""
 
     @staticmethod
-    def forward(ctx, x, addmask, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, F, R):
+    def forward(ctx, x, addmask, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, F, R, f2b_below=None, f2b_from_above=False):
+        """``f2b_below`` / ``f2b_from_above`` (ObjectTransformer.forward_features, blocks chained output -> input): the gradient
+        entering the block below IS the dx this block's norm1 backward writes, so the column sums of that dx -- the gradient of the
+        lower block's fc2 bias -- come out of the LayerNorm-backward kernel that produces it, and the lower block skips its own
+        column-sum pass over the same 28 MB (12 launches of ~11 us per step)."""
         B, N, D = x.shape
         cd = x.dtype
         x2 = x.reshape(B * N, D)
         h1, _, m1, r1 = ops.layernorm_fwd(x2, n1w.detach(), n1b.detach(), 1e-6)
         qkv = ops.linear_fwd(h1, SHADOWS.get(qkvw, cd), qkvb.detach())
-        att = ops.space_attention_fwd(qkv, addmask, B, F, R)
+        att, cls_stats = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True)
         x1 = ops.linear_fwd(att, SHADOWS.get(pw, cd), pb.detach(), res=x2)
         h2, _, m2, r2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), 1e-6)
         pre = torch.empty((B * N, f1w.shape[0]), device=x.device, dtype=cd)
         a = ops.linear_fwd(h2, SHADOWS.get(f1w, cd), f1b.detach(), gelu_aux=pre)
         y = ops.linear_fwd(a, SHADOWS.get(f2w, cd), f2b.detach(), res=x1)
-        ctx.save_for_backward(x2, addmask, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a)
+        ctx.save_for_backward(x2, addmask, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a, cls_stats)
         ctx.params = (n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
         ctx.dims = (B, N, F, R)
+        ctx.f2b_below, ctx.f2b_from_above = f2b_below, bool(f2b_from_above)
         return y.reshape(B, N, D)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, addmask, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a = ctx.saved_tensors
+        x2, addmask, m1, r1, h1, qkv, att, x1, m2, r2, h2, pre, a, cls_stats = ctx.saved_tensors
         n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = ctx.params
         B, N, F, R = ctx.dims
         cd = x2.dtype
         dy2 = dy.reshape(B * N, -1).contiguous()
-        df2b = _bgrad(dy2, f2b)
+        # the block above already queued colsum(dy) for this bias in its norm1 backward (same tensor: its dx is this dy)
+        df2b = _grad_buf(f2b) if ctx.f2b_from_above else _bgrad(dy2, f2b)
         dpre, df1b = _dx_with_bias_grad(dy2, SHADOWS.get(f2w, cd), pre, f1b)
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
         dx1, dn2w, dn2b, dpb = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2, bias_of_next=pb)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
-        dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R)
+        dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R, out=att, stats=cls_stats)
         dqkvb = _bgrad(dqkv, qkvb)
         dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
         # the four weight gradients of the block (9-36 output tiles each, K = B*N tokens) as ONE grouped GEMM
         df2w, df1w, dpw, dqkvw = _wgrad_group([(dy2, a, f2w), (dpre, h2, f1w), (dx1, att, pw), (dqkv, h1, qkvw)])
-        dx, dn1w, dn1b = _ln_bwd(dh1, x2, n1w, n1b, m1, r1, dres=dx1)
+        if ctx.f2b_below is not None:
+            dx, dn1w, dn1b, _ = _ln_bwd(dh1, x2, n1w, n1b, m1, r1, dres=dx1, bias_of_next=ctx.f2b_below)
+        else:
+            dx, dn1w, dn1b = _ln_bwd(dh1, x2, n1w, n1b, m1, r1, dres=dx1)
         _early_update((qkvw, pw, f1w, f2w))
-        return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None)
+        return (dx.reshape(B, N, -1), None, dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, df2w, df2b, None, None, None, None)
 
 
 class TimeSpaceBlockFn(torch.autograd.Function):

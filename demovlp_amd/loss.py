@@ -41,22 +41,32 @@ class RWALoss(nn.Module):
             s = s.to(im.dtype)
         return Fn.XattnFn.apply(im, s, im_m, s_m, float(self.lambda_softmax), self.focal_type == "equal")
 
-    def get_sim_by_segment(self, img_feats, lang_feats, img_mask, lang_length, cap_mask, segment=8, device="cpu"):
-        """Eval-time full grid (model/loss.py:73-103).  The reference walks 8x8 tiles in a Python loop; here the grid is
-        processed in row blocks sized by workspace (``segment`` is accepted for signature compatibility)."""
+    def get_sim_by_segment(self, img_feats, lang_feats, img_mask, lang_length, cap_mask, segment=8, device="cpu", precision=None):
+        """Eval-time full grid (model/loss.py:73-103) -> numpy float64 [n_img, n_txt].  The reference walks 8 x 8 tiles in a Python loop;
+        here the grid is processed in row blocks sized by workspace (``segment`` is accepted for signature compatibility).
+
+        ``precision`` (not in the reference's signature): ``None`` follows the embeddings -- fp32 embeddings take the fp32 multi-kernel
+        path (the 1e-4 parity path), bf16 embeddings the fused per-pair MFMA kernel (``xfused.hip``: S, both softmaxes, both context
+        products and the cosines of a pair stay on chip; G <= 288, W <= 112, else the bf16 multi-kernel path); ``'float32'`` /
+        ``'bfloat16'`` force one."""
         if not torch.cuda.is_available():
             raise DemoVLPHipError("get_sim_by_segment needs an MI355X device (no CPU fallback)")
         dev = torch.device("cuda")
+        if precision is None:
+            precision = "bfloat16" if img_feats.dtype == torch.bfloat16 and lang_feats.dtype == torch.bfloat16 else "float32"
+        if precision not in ("float32", "bfloat16"):
+            raise ValueError(f"precision must be None, 'float32' or 'bfloat16', got {precision!r}")
+        cd = torch.bfloat16 if precision == "bfloat16" else torch.float32
         n_img, n_txt = img_feats.shape[0], lang_feats.shape[0]
         sim = np.zeros((n_img, n_txt))
-        la = lang_feats.to(dev).float().contiguous()
+        la = lang_feats.to(dev).to(cd).contiguous()
         lam = cap_mask.to(dev).float().contiguous()
         G, W = img_feats.shape[1], lang_feats.shape[1]
-        per_img = n_txt * (G * (W + 8) * 3 + (W + 8) * 256 + G * 256) * 4          # rough bytes of workspace per image row
+        per_img = n_txt * (G * (W + 8) * 3 + (W + 8) * 256 + G * 256) * 4          # rough bytes of workspace per image row (multi-kernel path)
         rows = max(1, min(n_img, int(4e9 // max(per_img, 1))))
         with torch.no_grad():
             for i0 in range(0, n_img, rows):
-                im = img_feats[i0:i0 + rows].to(dev).float().contiguous()
+                im = img_feats[i0:i0 + rows].to(dev).to(cd).contiguous()
                 imm = img_mask[i0:i0 + rows].to(dev).float().contiguous()
                 out = Fn.XattnFn.apply(im, la, imm, lam, float(self.lambda_softmax), self.focal_type == "equal")
                 sim[i0:i0 + rows] = out.cpu().numpy()

@@ -60,7 +60,7 @@ class SpaceTimeBlock(nn.Module):
         self.mlp = Mlp(dim, hidden)
         self.norm3 = _Affine(dim)
 
-    def forward(self, x, addmask, frames, regions, addmask_t=None):
+    def forward(self, x, addmask, frames, regions, addmask_t=None, f2b_below=None, f2b_from_above=False):
         if self.time_module == "timeattn":
             t = self.timeattn
             return Fn.TimeSpaceBlockFn.apply(x, addmask, addmask_t, self.norm3.weight, self.norm3.bias, t.qkv.weight, t.qkv.bias,
@@ -70,7 +70,8 @@ class SpaceTimeBlock(nn.Module):
                                              self.mlp.fc2.bias, frames, regions)
         return Fn.VitBlockFn.apply(x, addmask, self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                                    self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight, self.norm2.bias,
-                                   self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, frames, regions)
+                                   self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, frames, regions,
+                                   f2b_below, f2b_from_above)
 
 
 class ObjectTransformer(nn.Module):
@@ -121,8 +122,21 @@ class ObjectTransformer(nn.Module):
                 leaf = tok.detach().requires_grad_(True)
                 self._cut = (tok, leaf)
                 tok = leaf
-            tok = blk(tok, addmask, F, R, addmask_t)
+            tok = blk(tok, addmask, F, R, addmask_t, **self._bias_grad_links(i))
         return tok, addmask
+
+    def _bias_grad_links(self, i):
+        """Blocks are chained output -> input here, so block i's norm1 backward can emit the fc2-bias gradient of block i - 1 (see
+        VitBlockFn.forward).  Only with gradient arenas attached (the sums are deferred reductions into the arena slice)."""
+        if self.time_module or not Fn.FUSE_LN_COLSUM or not torch.is_grad_enabled():
+            return {}
+
+        def linked(j):       # the pair (block j, block j + 1)
+            if j < 0 or j + 1 >= len(self.blocks):
+                return False
+            b, up = self.blocks[j].mlp.fc2.bias, self.blocks[j + 1].norm1
+            return all(getattr(t, "_dvlp_grad_view", None) is not None and t.requires_grad for t in (b, up.weight, up.bias))
+        return dict(f2b_below=self.blocks[i - 1].mlp.fc2.bias if linked(i - 1) else None, f2b_from_above=linked(i))
 
     def take_cut(self):
         """(tokens entering block ``grad_cut``, the leaf that replaced them) of the last forward, or None; clears it."""

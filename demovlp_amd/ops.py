@@ -273,26 +273,35 @@ HEADS, HEAD_DIM = 12, 64
 SCALE = HEAD_DIM ** -0.5
 
 
-def space_attention_fwd(qkv, addmask, B, F, R):
-    """qkv [B*N, 2304] packed (q | k | v), addmask [B,N] fp32 -> [B*N, 768]."""
+def space_attention_fwd(qkv, addmask, B, F, R, want_stats=False):
+    """qkv [B*N, 2304] packed (q | k | v), addmask [B,N] fp32 -> [B*N, 768].  ``want_stats`` (bf16): also the CLS query's softmax
+    statistics [B, H, 4] fp32 that :func:`space_attention_bwd` takes back with the output (the CLS query is then folded into the
+    per-frame waves in both directions); None in their place where the fold does not apply."""
     N = 1 + F * R
     out = torch.empty((B * N, 768), device=qkv.device, dtype=qkv.dtype)
     es = qkv.element_size()
     base = qkv.data_ptr()
+    stats, ws = None, None
+    if want_stats and qkv.dtype == torch.bfloat16 and (R + 15) // 16 == (R + 16) // 16 and R + 1 <= 48:
+        stats = torch.empty((B, HEADS, 4), device=qkv.device, dtype=torch.float32)
+        ws = _workspace("attn_fwd", B * HEADS * F * 66, qkv.device)
     call("dvlp_attention_fwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(base), ctypes.c_void_p(base + 768 * es),
-         ctypes.c_void_p(base + 1536 * es), 2304, p(addmask), p(out), 768, SCALE, stream())
-    return out
+         ctypes.c_void_p(base + 1536 * es), 2304, p(addmask), p(out), 768, SCALE, p(ws), p(stats), stream())
+    return (out, stats) if want_stats else out
 
 
-def space_attention_bwd(qkv, addmask, dout, B, F, R):
+def space_attention_bwd(qkv, addmask, dout, B, F, R, out=None, stats=None):
+    """``out`` / ``stats``: the forward's output and the statistics it returned (``want_stats``), or None."""
     N = 1 + F * R
     dqkv = torch.empty_like(qkv)
     es = qkv.element_size()
     b, db = qkv.data_ptr(), dqkv.data_ptr()
-    ws = _workspace("attn", B * HEADS * (F * 2 * 64 + 4), qkv.device)
+    ws = _workspace("attn", B * HEADS * (F * 3 * 64 + 4), qkv.device)
+    if stats is None:
+        out = None
     call("dvlp_attention_bwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(b), ctypes.c_void_p(b + 768 * es),
          ctypes.c_void_p(b + 1536 * es), 2304, p(addmask), p(dout), 768, ctypes.c_void_p(db), ctypes.c_void_p(db + 768 * es),
-         ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, stream())
+         ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, p(out), 768, p(stats), stream())
     return dqkv
 
 
@@ -303,7 +312,7 @@ def full_attention_fwd(q, k, v, addmask, B, L, ld=768, keep=None):
     out = torch.empty((B * L, 768), device=q.device, dtype=q.dtype)
     if keep is not None:
         call("dvlp_attention_dropout_next", p(keep[0]), p(keep[1]), float(keep[2]))
-    call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(out), 768, SCALE, stream())
+    call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(out), 768, SCALE, None, None, stream())
     return out
 
 
@@ -315,7 +324,7 @@ def full_attention_bwd(q, k, v, addmask, dout, B, L, ld=768, out=None, ld_out=76
     else:
         dq, dk, dv = out
     call("dvlp_attention_bwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
-         ld_out, None, SCALE, stream())
+         ld_out, None, SCALE, None, 0, None, stream())
     return dq, dk, dv
 
 

@@ -654,7 +654,7 @@ class GraphedTrainStep:
         return tuple(t.clone() for t in self.out)
 
 
-def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False, log=None):
+def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False, log=None, precision=None):
     """Retrieval evaluation of one validation loader, mirroring ``Multi_ObjectTrainer_dist._valid_epoch``
     (trainer/trainer_dist.py:205-408) on already-tokenised batches ``{'text': {input_ids, attention_mask}, 'object', 'object_mask'}``:
 
@@ -665,6 +665,8 @@ def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False
                              element-wise exactly as the reference does (it only type-checks on square eval sets); then every
                              metric on ``o2t_sims``.
 
+    ``precision`` is handed to ``get_sim_by_segment``: ``None`` (default) follows the model -- an fp32 model evaluates its grid on
+    the fp32 parity path, a bf16 model on the fused per-pair MFMA kernel; ``'float32'`` forces the parity path for a bf16 model.
     The embeddings stay in HBM (the reference parks them on the host between batches; 1000 MSRVTT pairs are 0.35 GB here).
     Returns ``{'val_loss', 'o2t_sims' (numpy [N,N]), 'global_sims', 'local_sims', 'nested_val_metrics': {name: dict}}``."""
     from . import metric as M
@@ -697,7 +699,8 @@ def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False
         global_sims = sim_matrix(cat["gt"], cat["go"]).detach().float().cpu().numpy()
         o2t_sims, local_sims = global_sims, None
         if use_local:
-            local_sims = loss_fn.local_loss.get_sim_by_segment(cat["lo"], cat["lt"], cat["om"], cat["len"], cat["tm"], device=cat["lo"].device)
+            local_sims = loss_fn.local_loss.get_sim_by_segment(cat["lo"], cat["lt"], cat["om"], cat["len"], cat["tm"], device=cat["lo"].device,
+                                                               precision=precision)
             o2t_sims = global_sims + local_sims                 # [n_text, n_video] + [n_video, n_text]: the reference's addend quirk
     if was_training:
         model.train()

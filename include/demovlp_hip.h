@@ -83,7 +83,7 @@ int dvlp_prof_enable(int on);
 int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 
 /* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the
-   three-launch form -- for A/B measurements and tests.  Workspace of dvlp_attention_bwd (mode 0): B*H*(F*128 + 4) floats. */
+   three-launch form -- for A/B measurements and tests. */
 int dvlp_attention_bwd_variant(int merged);
 /* TIMING-ONLY ablation of the MFMA attention backward (1 no stores, 2 no exp, 4 stop after the softmax); 0 in production */
 int dvlp_attention_ablate(int bits);
@@ -114,11 +114,19 @@ int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int6
 
 /* ---- attention: VarAttention.forward + attn_mask (object_transformer.py:152-196, 91-97) [mode 0] and DistilBERT
  *      multi-head self-attention [mode 1]                                                                          ---- */
+/* `workspace` (B*H*F*66 floats) and `cls_stats` (B*H*4 floats), both optional (mode 0, bf16): the CLS query -- the one query that
+   attends to every key of the clip (object_transformer.py:162-167) -- is folded into the per-frame waves, merged flash-style by a
+   64-thread launch, and its softmax statistics stay in `cls_stats` for dvlp_attention_bwd (`fwd_out` = this call's `out`), which
+   then needs no statistics pass.  Backward workspace (mode 0): B*H*(F*192 + 4) floats. */
 int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
-                       const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, void* stream);
+                       const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
+                       float* cls_stats, void* stream);
 int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
                        const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk, void* dv,
-                       int64_t ldd, float* workspace, float scale, void* stream);
+                       int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out, const float* cls_stats,
+                       void* stream);
+/* 1 (default): fold the CLS query where workspaces are given; 0: separate CLS launches -- for A/B measurements and tests */
+int dvlp_attention_cls_fold(int on);
 
 /* ---- tower prologues: ObjectTransformer.forward_features (object_transformer.py:400-433); DistilBERT embeddings ---- */
 int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* box, void* stream);

@@ -401,14 +401,14 @@ def golden_qa(ref_model, ref_loss, ref_data, scratch):
 
 def golden_eval(ref_model, ref_loss, ref_data, scratch):
     """G9: the reference's retrieval evaluation (trainer/trainer_dist.py:205-408 with n_gpu = 1) on a synthetic MSRVTT-shape set:
-    configs/ft/msrvtt_o2t-select.json geometry (F=8, R=30), 96 video-caption pairs in batches of 32.  Per-batch validation loss,
+    configs/ft/msrvtt_o2t-select.json geometry (F=8, R=30), 256 video-caption pairs in batches of 32.  Per-batch validation loss,
     o2t_sims = sim_matrix(text, object) + get_sim_by_segment(local_object, local_text, ...) with the reference's own
     (transposed-addend) orientation, then t2v / v2t metrics from the reference's model/metric.py."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("refmetric", "/root/reference/model/metric.py")
     rm = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rm)
-    F, R, BS, NB = 8, 30, 32, 3
+    F, R, BS, NB = 8, 30, 32, 8                      # 256 pairs (round 3; 96 in round 2)
     m = build_reference_model(ref_model, F, R)
     m.eval()
     loss_fn = ref_loss.GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")

@@ -137,10 +137,11 @@ def test_colsum(dtype):
     assert rel(got, t.float().reshape(B, F, R, 768).sum((0, 2))) < tol(dtype)
 
 
-@pytest.fixture(params=[1, 0], ids=["bwd-one-pass", "bwd-three-launch"])
+@pytest.fixture(params=[2, 1, 0], ids=["cls-folded-fwd-and-bwd", "bwd-one-pass", "bwd-three-launch"])
 def attn_bwd_variant(request):
-    """bf16 space-attention backward: the one-pass form (CLS query folded into the frame tiles) and the three-launch form."""
-    ops.call("dvlp_attention_bwd_variant", request.param)
+    """bf16 space attention: the CLS query folded into the frame waves in forward AND backward (the forward's statistics handed to the
+    backward: what VitBlockFn runs), the one-pass backward with its own statistics launch, and the three-launch backward."""
+    ops.call("dvlp_attention_bwd_variant", 1 if request.param else 0)
     yield request.param
     ops.call("dvlp_attention_bwd_variant", 1)
 
@@ -154,12 +155,22 @@ def test_space_attention(dtype, B, F, R, attn_bwd_variant):
     addmask = torch.cat([torch.zeros(B, 1), (mask01 - 1) * 100], 1).to(DEV)
     q = qkv.float().reshape(B, N, 2304).clone().requires_grad_(True)
     ref = orc.space_attention(q, addmask, F, R)
-    out = ops.space_attention_fwd(qkv, addmask, B, F, R)
+    fold = attn_bwd_variant == 2
+    out, stats = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True) if fold else (ops.space_attention_fwd(qkv, addmask, B, F, R), None)
+    if fold and dtype == torch.bfloat16 and R in (36, 30, 15, 47):
+        assert stats is not None                                    # the fold did apply on these shapes
+        sref = (q.detach().reshape(B, N, 3, 12, 64)[:, 0, 0] * 0.125).unsqueeze(2) @ q.detach().reshape(B, N, 3, 12, 64)[:, :, 1].permute(0, 2, 3, 1)
+        sref = sref.squeeze(2) + addmask[:, None, :]                # CLS query's scores over all N keys, [B, H, N]
+        assert rel(stats[:, :, 0], sref.max(-1).values) < 2e-2 and rel(torch.log(stats[:, :, 1]), torch.log(torch.exp(sref - sref.max(-1, keepdim=True).values).sum(-1))) < 2e-2
     assert rel(out, ref.reshape(B * N, 768)) < tol(dtype)
     dout = rnd(B * N, 768, dtype=dtype, seed=2)
     ref.backward(dout.float().reshape(B, N, 768))
-    dqkv = ops.space_attention_bwd(qkv, addmask, dout, B, F, R)
+    dqkv = ops.space_attention_bwd(qkv, addmask, dout, B, F, R, out=out, stats=stats)
     assert rel(dqkv, q.grad.reshape(B * N, 2304)) < tol(dtype) * 2
+    # the CLS token's rows on their own (1 of N tokens: a wrong CLS row would hide inside the matrix-wide bound above)
+    cls_rows = torch.arange(B, device=DEV) * N
+    assert rel(out[cls_rows], ref.reshape(B * N, 768)[cls_rows]) < tol(dtype)
+    assert rel(dqkv[cls_rows], q.grad.reshape(B * N, 2304)[cls_rows]) < tol(dtype) * 2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -164,8 +164,9 @@ def test_ten_step_loss_curve_vs_reference(tag, lr):
 
 
 def test_eval_pipeline_vs_reference():
-    """G9: embeddings of 96 MSRVTT-shape pairs (F=8, R=30) -> sim_matrix + transposed local grid -> retrieval metrics, exactly as
-    trainer/trainer_dist.py:358-399 composes them."""
+    """G9: embeddings of 256 MSRVTT-shape pairs (F=8, R=30) -> sim_matrix + transposed local grid -> retrieval metrics, exactly as
+    trainer/trainer_dist.py:358-399 composes them.  The CPU oracle evaluates the local grid on the leading 48 x 48 block only (every
+    pair is independent; the whole 256 x 256 grid is checked on the device, tests/test_gpu_round2.py)."""
     from demovlp_amd import metric
     g = load_golden("g9_eval.npz")
     F, R, BS, NB = int(g["F"]), int(g["R"]), int(g["batch"]), int(g["batches"])
@@ -184,10 +185,11 @@ def test_eval_pipeline_vs_reference():
             assert np.abs(np.array([loss.item(), gl.item(), ll.item()]) - g["val_losses"][b]).max() < 1e-4 * max(1.0, g["val_losses"][b][0])
         cat = {k: torch.cat(v) for k, v in acc.items()}
         gs = orc.sim_matrix(cat["gt"], cat["go"]).numpy()
-        ls = orc.xattn_scores_batched(cat["lo"], cat["lt"], cat["om"].float(), cat["tm"]).numpy()
-    assert rel_err(gs, g["global_sims"]) < 1e-4 and rel_err(ls, g["local_sims"]) < 1e-4
-    o2t = gs + ls                                   # [text, video] + [video, text]: the reference's own orientation mix
-    assert rel_err(o2t, g["o2t_sims"]) < 1e-4
+        S = 48
+        ls = orc.xattn_scores_batched(cat["lo"][:S], cat["lt"][:S], cat["om"][:S].float(), cat["tm"][:S]).numpy()
+    assert rel_err(gs, g["global_sims"]) < 1e-4 and rel_err(ls, g["local_sims"][:S, :S]) < 1e-4
+    o2t = gs[:S, :S] + ls                           # [text, video] + [video, text]: the reference's own orientation mix
+    assert rel_err(o2t, g["o2t_sims"][:S, :S]) < 1e-4
     keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
     for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
         r = fn(g["o2t_sims"])

@@ -32,11 +32,13 @@ def main():
     dout = torch.randn(B * N, 768, device="cuda", generator=g).to(torch.bfloat16)
     mask = torch.zeros(B, N, device="cuda")
     mb = 2.0 * B * N * 2304 / 1e6
-    t = bench(lambda: ops.space_attention_fwd(qkv, mask, B, F, R))
-    print("space attention fwd  %7.1f us   (qkv read %.0f MB + out %.0f MB -> %.2f TB/s)" % (t, mb, mb / 3, (mb + mb / 3) / t))
-    t = bench(lambda: ops.space_attention_bwd(qkv, mask, dout, B, F, R))
-    print("space attention bwd  %7.1f us   (qkv + dout read, dqkv written: %.0f MB -> %.2f TB/s)" % (t, 2 * mb + mb / 3, (2 * mb + mb / 3) / t))
-
+    for fold in (0, 1):
+        ops.call("dvlp_attention_cls_fold", fold)
+        out, stats = ops.space_attention_fwd(qkv, mask, B, F, R, want_stats=True)
+        t = bench(lambda: ops.space_attention_fwd(qkv, mask, B, F, R, want_stats=True))
+        print("CLS fold %d: space attention fwd  %7.1f us   (qkv read %.0f MB + out %.0f MB -> %.2f TB/s)" % (fold, t, mb, mb / 3, (mb + mb / 3) / t))
+        t = bench(lambda: ops.space_attention_bwd(qkv, mask, dout, B, F, R, out=out, stats=stats))
+        print("CLS fold %d: space attention bwd  %7.1f us   (qkv + dout read, dqkv written: %.0f MB -> %.2f TB/s)" % (fold, t, 2 * mb + mb / 3, (2 * mb + mb / 3) / t))
 
 if __name__ == "__main__":
     main()
