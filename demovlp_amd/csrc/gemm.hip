@@ -129,11 +129,15 @@ __device__ __forceinline__ void epi_store8(const Epi& e, bf16* __restrict__ C, i
 // epi_store8 for a whole, aligned 8-column group with the operands it would load (bias, residual, aux-in) already in
 // registers: the 256-row kernel runs one workgroup per CU, so nothing hides a dependent load inside its store loop.
 // `fl` / `has_res` are e.flags / (e.res != null), or compile-time constants in the kernels specialised on the epilogue kind.
+// NOAB: alpha == 1 and the bias is already inside the accumulators (persistent form: they are initialised with it)
+template <bool NOAB = false>
 __device__ __forceinline__ void epi_store8_pre(const Epi& e, const int fl, const bool has_res, bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n,
                                                float (&v)[8], const float4 b0, const float4 b1, const bf16x8 r, const bf16x8 a) {
+    if constexpr (!NOAB) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] *= e.alpha;
-    if (e.bias) { v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
+        for (int t = 0; t < 8; ++t) v[t] *= e.alpha;
+        if (e.bias) { v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
+    }
     if (fl & EPI_GELU) {
         bf16x8 pre;
 #pragma unroll
@@ -874,14 +878,28 @@ constexpr int P8_EK_ANY = 4;
 // tiles give 73 x {3, 9, 12} = 219 / 657 / 876 tiles = 1 / 3 / 4 rounds on 256 CUs for 0.86 / 2.57 / 3.42 rounds of work, 224-row tiles
 // give 83 x {3, 9, 12} = 249 / 747 / 996 tiles: the same 1 / 3 / 4 rounds, each 7/8 as long.
 template <int MIH> constexpr int p8_tile_rows() { return 128 + 32 * MIH; }
-template <bool A_R, bool B_R, int EK, int MIH = 4>
+// Persistent form (PERS, gemm_bf16_p8p_kernel): one workgroup walks several tiles.  The unit stream is CONTINUOUS across tiles
+// (nk even, so a tile ends on a buffer-parity boundary): the last six phases of a tile already stage units 0..5 of the next one,
+// the epilogue's loads / stores are issued behind them and never waited for as a whole, and the next K loop starts on landed data.
+// vmcnt retires in issue order, so while the epilogue's operations are younger than the units a wait is for, they are simply ADDED
+// to the allowed count (p8_epi_ops: a LOWER bound of what the epilogue issues per wave -- a larger count would wait too little).
+// Only whole tiles (no ragged / split-K path: those would pull ~40 SGPRs and scratch into the loop; a scratch reload waits vmcnt(0)).
+struct P8Next { bool first; int64_t m0n, n0n; bool prev_counted; };     // (m0n, n0n): the next tile, or this tile again for the last one
+                                                                         // (the six units staged for nobody are drained at kernel end)
+template <int EK, int MIH> constexpr int p8_epi_ops() { return EK == 0 ? 2 * (4 + MIH) : (EK >= 1 && EK <= 3) ? 4 * (4 + MIH) : 0; }
+template <bool A_R, bool B_R, int EK, int MIH = 4, bool PERS = false>
 __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                         int64_t ldb, bf16* __restrict__ C, int64_t ldc, const Epi& e, int64_t m0, int64_t n0, int64_t kbeg, int nk,
-                                        float* __restrict__ slab_out, unsigned long long* st = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63;
+                                        float* __restrict__ slab_out, unsigned long long* st = nullptr, const P8Next nx = P8Next{true, 0, 0, false}) {
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    // persistent form: everything derived from the lane id (source pointers, fragment offsets, the epilogue's row / column offsets) is
+    // recomputed per tile; an opaque copy keeps the compiler from hoisting those registers out of the tile loop
+    if constexpr (PERS) asm volatile("" : "+v"(lane));
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int U = 4 * nk;
+    constexpr int EOPS = p8_epi_ops<EK, MIH>();
     static_assert(MIH == 4 || !A_R, "short tiles are only built for row-major (form K) A operands");
 
     // per-lane source pointers of this wave's two LDS-DMA pieces of every unit kind; they advance one K tile per use
@@ -901,29 +919,54 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     };
     using FA = std::integral_constant<bool, A_R>;
     using FB = std::integral_constant<bool, B_R>;
-    const bf16* sp[4][2];
+    // source cursors of the wave's LDS-DMA pieces: pointers in the one-tile form; in the persistent form 32-bit ELEMENT offsets from A / B
+    // (8 registers instead of 16 live across the K loop; the dispatch guarantees the operands span < 2^31 elements)
+    using Cur = std::conditional_t<PERS, unsigned, const bf16*>;
+    Cur sp[4][2];
+    auto cur_of = [&](const bf16* ptr, const bf16* base) -> Cur { if constexpr (PERS) return (unsigned)(ptr - base); else return ptr; };
+    auto set_ptrs = [&](int64_t m0_, int64_t n0_) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        sp[0][j] = src_ptr(FA{}, A, lda, m0, M, j);
-        sp[3][j] = src_ptr(FA{}, A, lda, m0 + 128, M, j);
-        sp[1][j] = src_ptr(FB{}, B, ldb, n0, N, j);
-        sp[2][j] = src_ptr(FB{}, B, ldb, n0 + 128, N, j);
-    }
+        for (int j = 0; j < 2; ++j) {
+            sp[0][j] = cur_of(src_ptr(FA{}, A, lda, m0_, M, j), A);
+            sp[3][j] = cur_of(src_ptr(FA{}, A, lda, m0_ + 128, M, j), A);
+            sp[1][j] = cur_of(src_ptr(FB{}, B, ldb, n0_, N, j), B);
+            sp[2][j] = cur_of(src_ptr(FB{}, B, ldb, n0_ + 128, N, j), B);
+        }
+    };
+    set_ptrs(m0, n0);          // PERS, follow-on tile: units 0..5 were staged by the previous tile; the cursors are rebuilt and advanced
+                               // below (cheaper than keeping them alive across the epilogue)
     const int64_t kstepA = A_R ? H_BK * lda : H_BK, kstepB = B_R ? H_BK * ldb : H_BK;
     auto stage = [&](auto kind_, int par) {
         constexpr int KIND = decltype(kind_)::value;
         char* dst = smem_raw + par * P_BUF + KIND * P_UNIT + wid * 2048;
-        p_glds(sp[KIND][0], dst);
-        p_glds(sp[KIND][1], dst + 1024);
+        const bf16* base = (KIND == 0 || KIND == 3) ? A : B;
+        if constexpr (PERS) { p_glds(base + sp[KIND][0], dst); p_glds(base + sp[KIND][1], dst + 1024); }
+        else { p_glds(sp[KIND][0], dst); p_glds(sp[KIND][1], dst + 1024); }
         const int64_t ks = (KIND == 0 || KIND == 3) ? kstepA : kstepB;
-        sp[KIND][0] += ks; sp[KIND][1] += ks;
+        sp[KIND][0] += (std::conditional_t<PERS, unsigned, int64_t>)ks; sp[KIND][1] += (std::conditional_t<PERS, unsigned, int64_t>)ks;
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     // prologue FIRST: units 0..5 (tile 0 and the first half of tile 1) are requested before anything else is set up, so the
     // accumulator clears and fragment-offset arithmetic below run under the memory latency instead of in front of it
-    stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0);
-    if (nk > 1) { stage(I0{}, 1); stage(I1{}, 1); }
+    auto stage_bias = [&](int64_t n0_) {           // PERS: 256 fp32 bias values of a tile -> this wave's LDS copy (one LDS-DMA instruction)
+        if (e.bias) p_glds((const bf16*)(e.bias + n0_ + 4 * lane), smem_raw + P_LDS + wid * 1024);
+    };
+    // persistent form: EIGHT units (two whole K tiles) are ahead of every tile's first phase -- units 0..5 from the previous tile's last
+    // phases, 6 and 7 from behind its K loop -- so that the epilogue's stores, which sit in the vmcnt queue behind them, are first
+    // waited for in phase 7 (the first wait that needs a unit younger than they are)
+    if (!PERS || nx.first) {
+        if constexpr (PERS) stage_bias(n0);
+        stage(I0{}, 0); stage(I1{}, 0); stage(I2{}, 0); stage(I3{}, 0);
+        if (nk > 1) { stage(I0{}, 1); stage(I1{}, 1); }
+        if constexpr (PERS) { stage(I2{}, 1); stage(I3{}, 1); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            using D = std::conditional_t<PERS, unsigned, int64_t>;
+            sp[0][j] += (D)(2 * kstepA); sp[1][j] += (D)(2 * kstepB); sp[2][j] += (D)(2 * kstepB); sp[3][j] += (D)(2 * kstepA);
+        }
+    }
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -1005,14 +1048,28 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
     };
 
-    auto phase = [&](auto q_, auto par_, int P) {
-        constexpr int Q = decltype(q_)::value, PAR = decltype(par_)::value;
+    // VAR: 0 = one-tile form (run-time tail handling); persistent form, K-tile pairs of a tile: 1 = first (the previous epilogue's
+    // operations may sit in the queue), 2 = middle, 3 = last (switches to the next tile's units at phase U - 6 = (q 2, parity 0))
+    auto phase = [&](auto q_, auto par_, auto var_, int P) {
+        constexpr int Q = decltype(q_)::value, PAR = decltype(par_)::value, VAR = decltype(var_)::value;
         // ---- load segment: fragment reads of this phase, one unit of prefetch, counted wait for what the NEXT phase reads
         if constexpr (Q == 0) { read_b(par_, I1{}, bL, bllo, blhi); read_a(par_, I0{}); }
         if constexpr (Q == 1) read_b(par_, I2{}, bH, bhlo, bhhi);
         if constexpr (Q == 2) read_a(par_, I3{});
-        if (P + 6 < U) stage(std::integral_constant<int, (Q + 2) & 3>{}, Q < 2 ? (PAR ^ 1) : PAR);
-        if constexpr (Q != 2) p_wait_units(U - 3 - P);
+        if constexpr (VAR == 0) {
+            if (P + 6 < U) stage(std::integral_constant<int, (Q + 2) & 3>{}, Q < 2 ? (PAR ^ 1) : PAR);
+            if constexpr (Q != 2) p_wait_units(U - 3 - P);
+        } else {
+            if constexpr (VAR == 3 && Q == 2 && PAR == 0) { set_ptrs(nx.m0n, nx.n0n); stage_bias(nx.n0n); }
+            // (phases 0 and 1 of a tile stage nothing: units 6 and 7 are already on their way)
+            if constexpr (!(VAR == 1 && PAR == 0 && Q < 2)) stage(std::integral_constant<int, (Q + 2) & 3>{}, Q < 2 ? (PAR ^ 1) : PAR);
+            if constexpr (Q != 2) {
+                // four units stay in flight (five / four + the two early ones in phases 0 / 1: 8 is a lower bound there); through phase 5 of
+                // a follow-on tile the previous epilogue's operations sit between the units waited for and the youngest ones
+                if constexpr (VAR == 1 && !(PAR == 1 && Q == 3) && EOPS > 0) { if (nx.prev_counted) p_vmcnt<8 + EOPS>(); else p_vmcnt<8>(); }
+                else p_vmcnt<8>();
+            }
+        }
         __builtin_amdgcn_s_barrier();
         // ---- MFMA segment
         if constexpr (Q == 0) { land_b(bL, bllo, blhi); land_a(); }
@@ -1030,32 +1087,58 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
+    auto pair = [&](auto var_, int t) {
+        phase(I0{}, I0{}, var_, 4 * t + 0); phase(I1{}, I0{}, var_, 4 * t + 1); phase(I2{}, I0{}, var_, 4 * t + 2); phase(I3{}, I0{}, var_, 4 * t + 3);
+        phase(I0{}, I1{}, var_, 4 * t + 4); phase(I1{}, I1{}, var_, 4 * t + 5); phase(I2{}, I1{}, var_, 4 * t + 6); phase(I3{}, I1{}, var_, 4 * t + 7);
+    };
 
     // wait for units 0 and 1 of the prologue issued at the top
-    if (nk > 1) p_vmcnt<8>(); else p_vmcnt<4>();
+    if (PERS && EOPS > 0 && nx.prev_counted) p_vmcnt<8 + EOPS>();            // units 2..5 and the previous tile's epilogue may still be in flight
+    else if (nk > 1) p_vmcnt<8>(); else p_vmcnt<4>();
+    if constexpr (PERS) {
+        // accumulators start from the bias (alpha == 1): this wave's own 1-KiB copy of the tile's 256 bias values, staged by LDS-DMA ahead
+        // of the tile's unit 0 (so the wait above covers it) -- the epilogue then has no load the compiler would close with vmcnt(0)
+        if (e.bias) {
+            const float* bl = (const float*)(smem_raw + P_LDS + wid * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b4 = *(const f32x4*)(bl + 32 * wc + 16 * (j & 1) + 128 * (j >> 1) + 4 * (lane >> 4));
+#pragma unroll
+                for (int i = 0; i < 4 + MIH; ++i) acc[i][j] = b4;
+            }
+        }
+    }
     __builtin_amdgcn_s_barrier();
     P8_STAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs one barrier behind group 0
-    for (int t = 0; t < nk; t += 2) {
-        phase(I0{}, I0{}, 4 * t + 0); phase(I1{}, I0{}, 4 * t + 1); phase(I2{}, I0{}, 4 * t + 2); phase(I3{}, I0{}, 4 * t + 3);
-        if (t + 1 < nk) {
-            phase(I0{}, I1{}, 4 * t + 4); phase(I1{}, I1{}, 4 * t + 5); phase(I2{}, I1{}, 4 * t + 6); phase(I3{}, I1{}, 4 * t + 7);
+    if constexpr (PERS) {                                      // nk even, >= 4
+        pair(I1{}, 0);
+#pragma unroll 1
+        for (int t = 2; t < nk - 2; t += 2) pair(I2{}, t);
+        pair(I3{}, nk - 2);
+    } else {
+        for (int t = 0; t < nk; t += 2) {
+            phase(I0{}, I0{}, I0{}, 4 * t + 0); phase(I1{}, I0{}, I0{}, 4 * t + 1); phase(I2{}, I0{}, I0{}, 4 * t + 2); phase(I3{}, I0{}, I0{}, 4 * t + 3);
+            if (t + 1 < nk) {
+                phase(I0{}, I1{}, I0{}, 4 * t + 4); phase(I1{}, I1{}, I0{}, 4 * t + 5); phase(I2{}, I1{}, I0{}, 4 * t + 6); phase(I3{}, I1{}, I0{}, 4 * t + 7);
+            }
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                 // re-align the groups: every LDS read and DMA has retired
     P8_STAMP(2);
+    if constexpr (PERS) { stage(I2{}, 1); stage(I3{}, 1); }    // the next tile's units 6 and 7 (their slots were last read two phases ago)
 
     // Epilogue, per wave and without workgroup barriers.  The products above are issued with the B fragment as the FIRST MFMA
     // operand, so the accumulator tile is C^T: lane (g = lane / 16, r = lane % 16) holds acc[i][j][0..3] = C[row 16 i' + r][columns
     // 16 j' + 4 g + 0..3] -- four CONSECUTIVE columns of one row.  fp32 outputs (split-K slabs) leave as 16-byte stores as they are;
     // for bf16 one v_permlane16_swap per register pairs the two 16-column blocks so that a lane owns 8 consecutive columns
     // (16 bytes) and a store instruction writes 16 rows x 64 contiguous bytes.  No LDS round trip (it was ~20 % of a K = 768 product).
-    const int ab = e.flags >> 24;    // timing ablations (0 in production): 8 no stores, 16 no epilogue, 32 stores hit 256 rows only, 64 no nt
+    const int ab = PERS ? 0 : e.flags >> 24;    // timing ablations (0 in production): 8 no stores, 16 no epilogue, 32 stores hit 256 rows only, 64 no nt
     if (ab & 16) { if (acc[0][0][0] == 123.456f && acc[7][3][3] == 1.f) C[0] = (bf16)1.f; return; }
     if (ab & 8) M = 0;
     const int r16 = lane & 15, g4 = lane >> 4;
     auto row_of = [&](int ii) { return m0 + (ii < 4 ? 64 * wr : 128 + 16 * MIH * wr) + 16 * (ii & 3) + r16; };
-    if (slab_out && n0 + 256 <= N && (N & 3) == 0) {
+    if (!PERS && slab_out && n0 + 256 <= N && (N & 3) == 0) {
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii) {
             const int64_t m = row_of(ii);
@@ -1067,7 +1150,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
         return;
     }
-    const bool whole = e.vec && n0 + 256 <= N && !slab_out;   // every 8-column group of this block is whole and 16-byte aligned
+    const bool whole = PERS || (e.vec && n0 + 256 <= N && !slab_out);   // every 8-column group of this block is whole and 16-byte aligned
     if (whole) {
         const int fl = EK == P8_EK_ANY ? e.flags : EK == 2 ? EPI_GELU : EK == 3 ? EPI_GELU_BWD : (e.flags & EPI_LEAKY);   // LeakyReLU: no loads, stays a run-time test
         const bool has_res = EK == P8_EK_ANY ? e.res != nullptr : EK == 1, has_aux = (fl & (EPI_GELU_BWD | EPI_RELU_BWD)) != 0;
@@ -1076,7 +1159,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             bb[hh][0] = make_float4(0.f, 0.f, 0.f, 0.f); bb[hh][1] = bb[hh][0];
-            if (e.bias) { bb[hh][0] = *(const float4*)(e.bias + cn0 + 128 * hh); bb[hh][1] = *(const float4*)(e.bias + cn0 + 128 * hh + 4); }
+            if (!PERS && e.bias) { bb[hh][0] = *(const float4*)(e.bias + cn0 + 128 * hh); bb[hh][1] = *(const float4*)(e.bias + cn0 + 128 * hh + 4); }
         }
         float cs[2][8];                                    // e.csum: this lane's column sums over the rows it stores
 #pragma unroll
@@ -1109,15 +1192,15 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
                     v[t] = __uint_as_float(sw[0]); v[4 + t] = __uint_as_float(sw[1]);
                 }
                 if (m < M) {
-                    epi_store8_pre(e, fl, has_res, C, ldc, (EK == P8_EK_ANY && (ab & 32)) ? (m & 255) : m, cn0 + 128 * hh, v, bb[hh][0], bb[hh][1], pr[ii & 3][hh], pa[ii & 3][hh]);
-                    if (e.csum) {
+                    epi_store8_pre<PERS>(e, fl, has_res, C, ldc, (EK == P8_EK_ANY && (ab & 32)) ? (m & 255) : m, cn0 + 128 * hh, v, bb[hh][0], bb[hh][1], pr[ii & 3][hh], pa[ii & 3][hh]);
+                    if (!PERS && e.csum) {
 #pragma unroll
                         for (int t = 0; t < 8; ++t) cs[hh][t] += v[t];
                     }
                 }
             }
         }
-        if (e.csum) {
+        if (!PERS && e.csum) {
             // the 16 lanes of a row group hold the same 8 columns for different rows: combine, one partial row per wave
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -1132,7 +1215,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
         return;
     }
-    if constexpr (MIH != 4) return;      // short tiles are only dispatched when every tile takes the path above
+    if constexpr (MIH != 4 || PERS) return;      // short tiles / the persistent form are only dispatched when every tile takes the path above
     // ragged tiles / unaligned outputs: four 32-row passes through LDS (rows {lo, hi} x {first, second 32}; a pass covers the
     // wave's 32 + 32 columns), scalar epilogue out of line
     constexpr int P_EPW = 32 * 68 * 4;                         // bytes per wave: staged accumulators
@@ -1188,6 +1271,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
 #else
     p8_tile<A_R, B_R, EK, MIH>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * p8_tile_rows<MIH>(), (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);
 #endif
+}
+
+// Persistent form of the kernel above for outputs of more than one round of tiles (one workgroup per CU, workgroup w takes tiles
+// w, w + G, ...).  What it removes per tile (tools/p8_timeline.py, K = 768: 18 us of K loop in a 24-32 us tile): the 2 us between
+// entry and the first landed data (the next tile's first six units are staged by the previous tile's last phases) and the 0.6-3 us
+// between two workgroups on a CU; the epilogue's stores drain under the next tile's first phases.
+template <bool A_R, bool B_R, int EK, int MIH>
+__global__ __launch_bounds__(512) void gemm_bf16_p8p_kernel(int64_t M, int64_t N, int64_t K, const bf16* __restrict__ A, int64_t lda,
+                                                            const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                            Epi e, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TH = p8_tile_rows<MIH>();
+    const int T = ntm * ntn, G = (int)gridDim.x, w = (int)blockIdx.x;
+    const int cnt = (T - w + G - 1) / G;
+    const int nk = (int)(K / H_BK);
+    int tm_, tn_;
+    tile_of32(xcd_remap32(w, T), ntm, ntn, tm_, tn_);
+    bool prev_counted = false;
+#pragma unroll 1
+    for (int i = 0; i < cnt; ++i) {
+        int tmn = tm_, tnn = tn_;                                // last tile: stage its own first units again (never read)
+        if (i + 1 < cnt) tile_of32(xcd_remap32(w + (i + 1) * G, T), ntm, ntn, tmn, tnn);
+        const P8Next nx{i == 0, (int64_t)tmn * TH, (int64_t)tnn * 256, prev_counted};
+        p8_tile<A_R, B_R, EK, MIH, true>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * TH, (int64_t)tn_ * 256, 0, nk, nullptr, nullptr, nx);
+        prev_counted = (int64_t)tm_ * TH + TH <= M;              // every wave issued its full set of epilogue operations
+        tm_ = tmn; tn_ = tnn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the units staged for nobody must land before this CU's LDS is handed on
 }
 
 // Grouped weight gradients: up to P8G_MAX independent dW_p = dY_p^T X_p products (all form R x form R, fp32 out) in ONE
@@ -1302,6 +1413,8 @@ static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile pat
 extern "C" int dvlp_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
 extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
+static int g_p8_persist = 0;     // persistent form of the 256-row kernel on multi-round outputs: 0 off, 1 on (A/B: tools/p8p_bench.py)
+extern "C" int dvlp_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
 static int g_p8_short = 1;       // 224-row tiles of the 256-row kernel: 0 never, 1 where they save CU-rounds (default), 2 whenever allowed
 extern "C" int dvlp_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
 static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
@@ -1475,7 +1588,12 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
             (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AR, BR, EK, MIH>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
         hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR, EK, MIH>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn8, kchunk, slab); } while (0)
-#define LAUNCH_P8S_(AR, BR, EK) do { if constexpr (!AR) { if (mih8 == 3) { LAUNCH_P8K_(AR, BR, EK, 3); break; } } LAUNCH_P8K_(AR, BR, EK, 4); } while (0)
+#define LAUNCH_P8P_(AR, BR, EK, MIH) do { static bool once = false; if (!once) { once = true; \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8p_kernel<AR, BR, EK, MIH>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS + 8192); } \
+        hipLaunchKernelGGL((gemm_bf16_p8p_kernel<AR, BR, EK, MIH>), dim3((unsigned)ncu8), dim3(512), (size_t)(P_LDS + 8192), st, M, N, K, (const bf16*)A, lda, \
+                           (const bf16*)B, ldb, (bf16*)C, ldc, e, (int)ntm8h, (int)ntn8); } while (0)
+#define LAUNCH_P8S_(AR, BR, EK) do { if constexpr (!AR && (EK == 0 || EK == 2)) { if (p8p) { LAUNCH_P8P_(AR, BR, EK, 3); break; } } if constexpr (!AR) { \
+        if (mih8 == 3) { LAUNCH_P8K_(AR, BR, EK, 3); break; } } LAUNCH_P8K_(AR, BR, EK, 4); } while (0)
 #define LAUNCH_P8_(AR, BR) do { if (ek8 == 0) LAUNCH_P8S_(AR, BR, 0); else if (ek8 == 1) LAUNCH_P8S_(AR, BR, 1); else if (ek8 == 2) LAUNCH_P8S_(AR, BR, 2); \
         else if (ek8 == 3) LAUNCH_P8S_(AR, BR, 3); else LAUNCH_P8K_(AR, BR, P8_EK_ANY, 4); } while (0)
 #define LAUNCH_GLDS_(AR, BR) do { if (p8) LAUNCH_P8_(AR, BR); else if (wide) { static bool once = false; if (!once) { once = true; \
@@ -1507,6 +1625,9 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
             csum_fused = e.csum != nullptr;
         }
         dim3 grid8((unsigned)(ntm8h * ntn8), (unsigned)batch, (unsigned)S);
+        // persistent form: more than one round of whole tiles, an even number (>= 4) of K tiles, a specialised epilogue, no fused column sums
+        const bool p8p = p8 && g_p8_persist != 0 && mih8 == 3 && M * lda < (1ll << 31) && N * ldb < (1ll << 31) && K * ldb < (1ll << 31) && !transA && S == 1 && batch == 1 && ntm8h * ntn8 > ncu8 && N % 256 == 0 && e.vec && alpha == 1.0f &&
+                         (K / H_BK) % 2 == 0 && K / H_BK >= 4 && (ek8 == 0 || ek8 == 2) && !e.csum;      // (residual / aux-in epilogues: the compiler closes their loads with vmcnt(0) inside the tile loop)
 #define LAUNCH_BF16(AR, BR) do { if (dma) LAUNCH_GLDS_(AR, BR); else if (safe) LAUNCH_BF16_(AR, BR, true); else LAUNCH_BF16_(AR, BR, false); } while (0)
         rec.kern = p8 ? 2 : dma ? 1 : 0;
         if (!transA && !transB) LAUNCH_BF16(false, false);
@@ -1520,6 +1641,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
 #undef LAUNCH_GLDS_
 #undef LAUNCH_P8_
 #undef LAUNCH_P8S_
+#undef LAUNCH_P8P_
 #undef LAUNCH_P8K_
 #undef LAUNCH_BF16
     } else {

@@ -69,6 +69,10 @@ int dvlp_gemm_p8_mode(int mode);
 /* tile height of that kernel: 224-row tiles (the upper half of a tile 96 rows instead of 128) where they fill the CUs' rounds better than
    256-row ones -- 0 never, 1 (default) where rounds x rows is smaller, 2 whenever the operands allow; for A/B measurements and tests */
 int dvlp_gemm_p8_short_tiles(int mode);
+/* persistent form of that kernel on outputs of more than one round of tiles (one workgroup per CU walks its tiles; the next tile's first
+   units are staged by the previous tile's last phases, the epilogue's stores are not waited for): 0 (default) off, 1 on -- for A/B
+   measurements (tools/p8p_bench.py) and tests */
+int dvlp_gemm_p8_persistent(int mode);
 /* grouped weight gradients: 1 (default) blocks are dealt to the XCDs as 3 x 3 tile patches of one K slice, so a patch's operand panels are
    fetched into that XCD's L2 once; 0: per-problem tile order -- for A/B measurements */
 int dvlp_wgrad_group_patches(int on);

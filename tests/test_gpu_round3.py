@@ -487,3 +487,35 @@ def test_evaluate_mscoco_branch_subsamples_videos_and_passes_fold():
         evaluate(model, loss_head(), batches, use_local=False, mscoco=True)
     with pytest.raises(ValueError):                             # [n_text, n_video] + [n_video, n_text]: the reference's addend only adds up on square sets
         evaluate(model, loss_head(), batches, metrics=(t2v_fold,), use_local=True, mscoco=True)
+
+
+def test_persistent_gemm_kernel_agrees_with_the_one_tile_form():
+    """dvlp_gemm_p8_persistent(1) (opt-in): one workgroup per CU walks its 224-row tiles, the next tile's first eight units are staged
+    across the tile boundary, accumulators start from the bias.  Same products in the same order; the bias enters the fp32 sum first
+    instead of last, so outputs may differ by one bf16 rounding -- bounded here against an fp32 reference, plus a repeat screen of the
+    cross-tile prefetch (a race would show as run-to-run differences)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    bf = torch.bfloat16
+    M, N, K = 18496, 2304, 768
+    x = torch.randn(M, K, device=DEV, generator=g).to(bf)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(bf)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = x.float() @ w.float().t() + bias
+    try:
+        outs = {}
+        for mode in (0, 1):
+            ops.call("dvlp_gemm_p8_persistent", mode)
+            aux = torch.empty(M, N, device=DEV, dtype=bf)
+            outs[mode] = (ops.linear_fwd(x, w, bias), ops.linear_fwd(x, w, bias, gelu_aux=aux), aux, ops.linear_fwd(x, w, None))
+            if mode == 1:
+                for _ in range(10):
+                    again = ops.linear_fwd(x, w, bias)
+                    assert torch.equal(again, outs[1][0])
+        scale = float(ref.abs().max())
+        for a, b in zip(outs[0], outs[1]):
+            assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -7 * scale          # within one bf16 rounding of the largest value
+        assert torch.equal(outs[0][3], outs[1][3])                                           # no bias: bit-equal
+        assert float((outs[1][0].float() - ref).abs().max()) < 1e-2 * scale
+        assert float((outs[1][2].float() - ref).abs().max()) < 1e-2 * scale                 # pre-activation out of the GELU epilogue
+    finally:
+        ops.call("dvlp_gemm_p8_persistent", 0)
