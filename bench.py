@@ -29,7 +29,19 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FILES = ("r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
+TRAFFIC_FILES = ("r3_final_gemm_hbm_traffic_pmc.json", "r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
+
+
+def csrc_sha():
+    """sha256 over the kernel sources of the running tree (demovlp_amd/csrc/*): the committed PMC traffic figure is only reported
+    when it was measured on exactly these kernels (tools/profile_round.sh records the same hash beside the counters)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "demovlp_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def flops_per_pair(B, F, R, W=99, Lt=100):
@@ -119,28 +131,52 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def time_object_tower(model, data, steps, dist_sync):
+def time_object_tower(model, data, steps, dist_sync, graph=True):
     """ObjectTransformer alone, forward + backward (weight gradients included, no optimizer): seconds per pass.  This is the
-    quantity BASELINE.json's north_star prices at >= 40 % of the bf16 MFMA peak (151.55 GFLOP per pair at F=8, R=36)."""
+    quantity BASELINE.json's north_star prices at >= 40 % of the bf16 MFMA peak (151.55 GFLOP per pair at F=8, R=36).
+    ``graph``: the pass is captured once and replayed, like the step itself (the eager loop's ~350 launches cost the host about as
+    long as the device needs for them, so an eager figure is partly a host figure); falls back to eager launches if capture fails.
+    Returns (seconds per pass, "hipGraph replay" | "eager")."""
     import torch
     from demovlp_amd import functional as Fn, ops
     obj, mask = data["object"], data["object_mask"]
-    dy = None
-    t0 = 0.0
-    for it in range(steps + 2):
-        if it == 2:
-            dist_sync()
-            t0 = time.perf_counter()
+    state = {"dy": None}
+
+    def one():
         for p in model.object_model.parameters():
             p.grad = None
         emb, _ = model.object_model(obj, mask)
-        if dy is None:
-            dy = torch.randn(emb.shape, device=emb.device, dtype=torch.float32).mul_(1e-3).to(emb.dtype)
-        emb.backward(dy)
+        if state["dy"] is None:
+            state["dy"] = torch.randn(emb.shape, device=emb.device, dtype=torch.float32).mul_(1e-3).to(emb.dtype)
+        emb.backward(state["dy"])
         Fn.join_side_stream()
         ops.flush_reductions()
+
+    for _ in range(2):
+        one()
+    mode, g = "eager", None
+    if graph:
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one()
+            g.replay()
+            torch.cuda.synchronize()
+            mode = "hipGraph replay"
+        except Exception as e:  # noqa: BLE001
+            print("object tower: graph capture failed (%s), timing eager launches" % str(e)[:200], file=sys.stderr)
+            g = None
+            torch.cuda.synchronize()
     dist_sync()
-    return (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if g is not None:
+            g.replay()
+        else:
+            one()
+    dist_sync()
+    return (time.perf_counter() - t0) / steps, mode
 
 
 def main():
@@ -303,9 +339,9 @@ def main():
             dist.all_reduce(arena.flat_g)
         sync()
         allreduce_ms = round(1e3 * (time.perf_counter() - t1) / 3, 3)
-    obj_s = None
+    obj_s, obj_mode = None, None
     if not a.no_object_tower:
-        obj_s = time_object_tower(model, data, max(3, min(a.steps, 10)), sync)
+        obj_s, obj_mode = time_object_tower(model, data, max(3, min(a.steps, 10)), sync, graph=use_graph)
 
     if rank == 0:
         pairs = B * world * a.steps
@@ -333,36 +369,45 @@ def main():
             out["grad_allreduce_ms_standalone"] = allreduce_ms
             out["grad_allreduce_bytes"] = int(arena.flat_g.numel() * 4)
             if use_graph and getattr(stepper, "graph2", None) is not None:
-                early = sum(hi - lo for lo, hi in stepper.early_runs) * 4
-                out["grad_exchange"] = ("backward captured as two graphs cut at object block %d: %d MB (text tower + upper object blocks) all-reduced on a "
-                                        "communication stream while the second graph runs, %d MB behind it" % (stepper.cut, early >> 20, (arena.flat_g.numel() * 4 - early) >> 20))
-                out["launch_mode"] = out["launch_mode"].replace("1 graph per step", "2 graphs per step")
+                sizes = [sum(hi - lo for lo, hi in runs) * 4 >> 20 for runs in stepper.piece_runs]
+                out["grad_exchange"] = ("backward captured as %d graphs cut at object blocks %s: the gradients a piece finishes (%s MB: text tower + top blocks first, "
+                                        "lowest blocks + prologue + vector tail last) are all-reduced in %d MB buckets on a communication stream while the next graph "
+                                        "runs, and each reduced bucket goes straight to the fused optimizer on a third stream; only the last piece's exchange is exposed"
+                                        % (len(stepper.graphs), list(stepper.cuts), " / ".join(map(str, sizes)), stepper.bucket * 4 >> 20))
+                out["launch_mode"] = out["launch_mode"].replace("1 graph per step", "%d graphs per step" % len(stepper.graphs))
         if gemm_n:
             # HBM-side traffic per launch of the GEMM family cannot be self-measured from inside the process: it comes from
             # the committed rocprofv3 PMC passes of this same command, regenerated every round (tools/profile_round.sh)
-            traffic, traffic_src = None, None
+            traffic, traffic_src, traffic_note = None, None, None
             for fn in TRAFFIC_FILES:
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                    if a.dtype == "bf16" and B == 64 and F == 8 and R == 36:
-                        traffic = round(tj["gemm_family_traffic_bytes_per_launch"])
-                        traffic_src = "profiles/" + fn
-                    break
                 except Exception:
-                    pass
+                    continue
+                if not (a.dtype == "bf16" and B == 64 and F == 8 and R == 36):
+                    traffic_note = "the committed PMC passes are of the default workload (bf16, B=64, F=8, R=36)"
+                elif tj.get("csrc_sha") != csrc_sha():
+                    traffic_note = ("null: profiles/%s was measured on kernel sources %s (git %s), this tree's demovlp_amd/csrc hashes to %s -- re-run "
+                                    "tools/profile_round.sh" % (fn, tj.get("csrc_sha"), tj.get("git_head"), csrc_sha()))
+                else:
+                    traffic = round(tj["gemm_family_traffic_bytes_per_launch"])
+                    traffic_src = "profiles/%s (git %s, csrc %s)" % (fn, tj.get("git_head"), tj.get("csrc_sha"))
+                break
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline PMC pass)",
-                               "traffic_source": traffic_src,
+                               "traffic_source": traffic_src, **({"traffic_note": traffic_note} if traffic_note else {}),
                                "algorithmic_flops_per_launch": round(gemm_flops / gemm_n), "kernel": ("gemm_bf16_p8_kernel / gemm_bf16_p8_group_kernel / gemm_bf16_glds_kernel (all operand forms, incl. their split-K reductions)"
                                           if a.dtype == "bf16" else "gemm_f32_kernel (all forms)"),
                                "launches_per_step": gemm_n // a.steps, "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2),
-                               "gemm_share_of_step": round(gemm_ms * 1e-3 / my_elapsed, 3),
+                               # share of the region the launches were timed in (the eager pass behind a graph-replayed timed region)
+                               "gemm_share_of_step": round(gemm_ms * 1e-3 / (eager_ms * 1e-3 * a.steps if eager_ms is not None else my_elapsed), 3),
                                "timed_over": ("%d eager steps right behind the %d graph-replayed ones (%.3f ms/step eager)" % (a.steps, a.steps, eager_ms))
                                              if eager_ms is not None else "the timed region itself"}
             if obj_s is not None:
                 # north_star's target quantity: ObjectTransformer forward + backward alone, every kernel of it included
                 out["roofline"]["object_transformer_ms"] = round(1e3 * obj_s, 3)
+                out["roofline"]["object_transformer_launch_mode"] = obj_mode
                 out["roofline"]["object_transformer_tflops"] = round(B * fpp_obj / obj_s / 1e12, 2)
                 out["roofline"]["object_transformer_frac"] = round(B * fpp_obj / obj_s / 1e12 / peak, 4)
         if world == 1 and not a.no_cpu_baseline:

@@ -97,7 +97,7 @@ class ObjectTransformer(nn.Module):
         nn.init.trunc_normal_(self.custom_pos_embed, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.compute_dtype = torch.float32
-        self.grad_cut = None           # block index at which backward is cut in two (data-parallel graph step), None = one piece
+        self.grad_cut = None           # block index -- or several -- at which backward is cut (data-parallel graph step), None = one piece
         self._cut = None
 
     def forward_features(self, x, x_mask):
@@ -106,6 +106,7 @@ class ObjectTransformer(nn.Module):
             raise ValueError(f"expected {self.patches_per_frame} regions per frame, got {R}")
         if F > self.num_frames:
             raise ValueError(f"{F} frames > temporal_embed size {self.num_frames}")
+        self._cut = None
         obj = x.contiguous().float()
         mask01 = x_mask.reshape(B, F, R).contiguous().float()
         tok, addmask = Fn.ObjectPrologueFn.apply(obj, mask01, self.object_embedding.weight, self.object_embedding.bias,
@@ -115,12 +116,13 @@ class ObjectTransformer(nn.Module):
         if self.time_module == "timeattn":
             from . import ops
             addmask_t = ops.token_transpose(addmask.reshape(B, 1 + F * R, 1), B, F, R).reshape(B, 1 + F * R)     # key mask in region-major order
+        cuts = () if self.grad_cut is None else ((self.grad_cut,) if isinstance(self.grad_cut, int) else tuple(self.grad_cut))
         for i, blk in enumerate(self.blocks):
-            if self.grad_cut is not None and i == self.grad_cut and tok.requires_grad and torch.is_grad_enabled():
-                # backward in two pieces (trainer.backward_first / backward_second): autograd stops at this leaf, the caller exchanges
-                # the gradients that are final by then, and resumes from the leaf's gradient
+            if i in cuts and tok.requires_grad and torch.is_grad_enabled():
+                # backward in pieces (trainer.backward_first / backward_next): autograd stops at this leaf, the caller exchanges the
+                # gradients that are final by then, and resumes from the leaf's gradient
                 leaf = tok.detach().requires_grad_(True)
-                self._cut = (tok, leaf)
+                self._cut = (self._cut or []) + [(tok, leaf)]
                 tok = leaf
             tok = blk(tok, addmask, F, R, addmask_t, **self._bias_grad_links(i))
         return tok, addmask
@@ -139,8 +141,14 @@ class ObjectTransformer(nn.Module):
         return dict(f2b_below=self.blocks[i - 1].mlp.fc2.bias if linked(i - 1) else None, f2b_from_above=linked(i))
 
     def take_cut(self):
-        """(tokens entering block ``grad_cut``, the leaf that replaced them) of the last forward, or None; clears it."""
-        cut, self._cut = self._cut, None
+        """The LAST open cut of the last forward -- (tokens entering that block, the leaf that replaced them) -- or None; pops it.  Cuts
+        are resumed from the top of the tower down, one per call."""
+        if not self._cut:
+            self._cut = None
+            return None
+        cut = self._cut.pop()
+        if not self._cut:
+            self._cut = None
         return cut
 
     def forward(self, x, x_mask):

@@ -440,16 +440,29 @@ def backward_first(model, loss_fn, data, gather_negatives=None):
     return loss.detach(), global_loss.detach(), local_loss.detach()
 
 
-def backward_second(model):
-    """The rest of a cut backward (no-op without a cut) + the batched final reduction of the bias / LayerNorm gradients."""
+def backward_next(model):
+    """Resume a cut backward by ONE piece: from the topmost open cut down to the next one (or to the inputs).  False when no cut is open."""
     om = getattr(model, "object_model", None)
     cut = om.take_cut() if om is not None and hasattr(om, "take_cut") else None
-    if cut is not None:
-        tok, leaf = cut
-        torch.autograd.backward(tok, leaf.grad)
+    if cut is None:
+        return False
+    tok, leaf = cut
+    torch.autograd.backward(tok, leaf.grad)
+    return True
+
+
+def finish_backward(model):
+    """The batched final reduction of the bias / LayerNorm gradients (after the last piece of the backward)."""
     if torch.cuda.is_available() and next(model.parameters()).is_cuda:
         Fn.join_side_stream()          # deferred partial sums may have been produced on the side stream
         ops.flush_reductions()
+
+
+def backward_second(model):
+    """The rest of a cut backward (every open piece; no-op without a cut) + the batched final reduction."""
+    while backward_next(model):
+        pass
+    finish_backward(model)
 
 
 def forward_backward(model, loss_fn, data, gather_negatives=None):
@@ -487,19 +500,22 @@ def train_step(model, loss_fn, optimizer, data, reducer: GradReducer | None = No
 
 
 class GraphedTrainStep:
-    """``train_step`` as ONE hipGraph: after ``warmup`` eager steps (kernel attributes set, workspaces allocated, the deferred-
+    """``train_step`` as hipGraph replays: after ``warmup`` eager steps (kernel attributes set, workspaces allocated, the deferred-
     reduction table uploaded, the grad-less tensors learnt) the next step is captured -- forward, losses, backward, the batched
     final reduction, fused AdamW: ~520 launches -- and every later call copies the batch into the captured input buffers and
     replays.  The host's per-launch Python / ctypes / autograd cost (~40 us x 520) disappears from the step.
 
-    Data parallel (``world > 1``): no collective is captured.  The backward is cut in two at object block ``cut`` and captured as TWO
-    graphs: when the first has run, the text tower's and the upper object blocks' weight gradients (~70 % of the bytes, contiguous
-    arena ranges) are final and their all-reduce is issued on a communication stream while the second graph -- the lower object
-    blocks -- runs; only the rest (lower blocks, embeddings, the vector tail) is exchanged behind the second graph, and the optimizer
-    launch follows eagerly.  Static shapes only: a batch of another shape re-captures."""
+    Data parallel (``world > 1``): no collective is captured.  The backward is cut at the object blocks ``cut`` (an index or several,
+    default (8, 4)) and captured as ``len(cut) + 1`` graphs sharing one memory pool.  When piece k has run, the weight gradients it
+    produced are final -- piece 0: the text tower and the object blocks above the first cut (contiguous arena runs), piece k: the
+    blocks between two cuts, last piece: the lowest blocks, the prologue and the vector tail -- and their exchange starts at once:
+    every run is all-reduced in ``bucket_mb`` pieces on the communication stream while the NEXT graph runs, and each piece is
+    handed to the fused optimizer on a third stream the moment its reduction completes (``adamw_range_dev``; the 1 / world average
+    is folded into its grad_scale), so neither the optimizer nor any exchange but the last piece's (blocks 0-3 + prologue: ~20 % of
+    the bytes at the default cuts) waits for the whole arena.  Static shapes only: a batch of another shape re-captures."""
 
-    def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 256.0, always_reduce: bool = False,
-                 cut: int | None = 6):
+    def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 64.0, always_reduce: bool = False,
+                 cut=(8, 4)):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.warmup, self.calls = max(1, warmup), 0
         self.group = group
@@ -507,35 +523,74 @@ class GraphedTrainStep:
         self.bucket = int(bucket_mb * 1024 * 1024 / 4)
         # always_reduce: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
         self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
-        self.graph, self.graph2, self.static, self.out, self.shape_key = None, None, None, None, None
-        self.cut, self.early_runs, self.late_runs, self._comm = None, [], [(0, optimizer.arena.total)], None
+        self.graphs, self.static, self.out, self.shape_key = None, None, None, None
+        self.cuts, self.piece_runs, self._comm, self._optst = (), [[(0, optimizer.arena.total)]], None, None
         om = getattr(model, "object_model", None)
-        if self.collective and cut and om is not None and hasattr(om, "grad_cut") and 0 < cut < len(om.blocks):
-            self.cut = int(cut)
-            self.early_runs, self.late_runs = self.plan_exchange(optimizer.arena, self.cut)
+        if self.collective and cut and om is not None and hasattr(om, "grad_cut"):
+            cuts = sorted({int(c) for c in ((cut,) if isinstance(cut, int) else cut) if 0 < int(c) < len(om.blocks)}, reverse=True)
+            if cuts:
+                self.cuts = tuple(cuts)
+                self.piece_runs = self.plan_exchange(optimizer.arena, self.cuts)
+
+    # kept for callers / tests of the two-piece form
+    @property
+    def cut(self):
+        return self.cuts[0] if self.cuts else None
+
+    @property
+    def graph(self):
+        return self.graphs[0] if self.graphs else None
+
+    @property
+    def graph2(self):
+        return self.graphs[1] if self.graphs and len(self.graphs) > 1 else None
+
+    @property
+    def early_runs(self):
+        return [r for runs in self.piece_runs[:-1] for r in runs]
+
+    @property
+    def late_runs(self):
+        return self.piece_runs[-1]
 
     @staticmethod
-    def plan_exchange(arena, cut):
-        """Arena ranges whose gradients are final after the first piece of a backward cut at object block ``cut`` (the text tower's
-        matrices and object blocks >= cut: two contiguous runs in the arena's matrices-first order), and the complement."""
-        def early(n):
-            return n.startswith("text_model.") or (n.startswith("object_model.blocks.") and int(n.split(".")[2]) >= cut)
-        runs = []
+    def plan_exchange(arena, cuts):
+        """Arena ranges whose gradients are final after each piece of a backward cut at object blocks ``cuts`` (descending): piece 0 =
+        the text tower's matrices and the object blocks >= cuts[0]; piece k = blocks in [cuts[k], cuts[k-1]); the last piece = the
+        complement (lowest blocks, prologue, heads written late, the vector tail).  Every element of the arena is in exactly one piece."""
+        cuts = (cuts,) if isinstance(cuts, int) else tuple(cuts)
+        bounds = [len(cuts) and 10 ** 9] + list(cuts)
+
+        def piece_of(n):
+            if n.startswith("text_model."):
+                return 0
+            if n.startswith("object_model.blocks."):
+                blk = int(n.split(".")[2])
+                for k in range(len(cuts)):
+                    if cuts[k] <= blk < bounds[k]:
+                        return k
+            return len(cuts)
+        pieces = [[] for _ in range(len(cuts) + 1)]
         for i in range(arena.n_matrix):
-            if early(arena.names[i]):
-                lo = arena.offsets[i]
-                hi = lo + (arena.params[i].numel() + arena.ALIGN - 1) // arena.ALIGN * arena.ALIGN
-                if runs and runs[-1][1] == lo:
-                    runs[-1][1] = hi
-                else:
-                    runs.append([lo, hi])
-        runs = [(lo, hi) for lo, hi in runs if hi - lo >= (1 << 18)]          # tiny runs are not worth a collective of their own
-        late, pos = [], 0
-        for lo, hi in runs + [(arena.total, arena.total)]:
+            k = piece_of(arena.names[i])
+            if k == len(cuts):
+                continue
+            lo = arena.offsets[i]
+            hi = lo + (arena.params[i].numel() + arena.ALIGN - 1) // arena.ALIGN * arena.ALIGN
+            if pieces[k] and pieces[k][-1][1] == lo:
+                pieces[k][-1][1] = hi
+            else:
+                pieces[k].append([lo, hi])
+        early = sorted((lo, hi, k) for k in range(len(cuts)) for lo, hi in pieces[k] if hi - lo >= (1 << 18))   # tiny runs ride with the last piece
+        out = [[] for _ in range(len(cuts) + 1)]
+        pos = 0
+        for lo, hi, k in early + [(arena.total, arena.total, len(cuts))]:
             if lo > pos:
-                late.append((pos, lo))
+                out[len(cuts)].append((pos, lo))
+            if hi > lo:
+                out[k].append((lo, hi))
             pos = hi
-        return runs, late
+        return out
 
     @staticmethod
     def _key(data):
@@ -546,87 +601,118 @@ class GraphedTrainStep:
             for p in range(lo, hi, self.bucket):
                 yield p, min(hi, p + self.bucket)
 
-    def _exchange(self, runs, overlapped=False):
-        """Sum the given arena ranges of the gradient buffer over the ranks; ``overlapped``: on the communication stream, behind
-        what the current stream holds so far -- returns the handles to wait on."""
-        g = self.opt.arena.flat_g
-        if not overlapped or not g.is_cuda:
-            for lo, hi in self._pieces(runs):
-                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-            return []
-        if self._comm is None:
-            self._comm = torch.cuda.Stream(device=g.device)
-        self._comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm):
-            return [dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in self._pieces(runs)]
-
-    def _allreduce(self):
-        self._exchange([(0, self.opt.arena.total)])
-
     def _set_cut(self, on=True):
         # only for this object's own forward: a caller that runs ``loss.backward()`` itself must get the whole backward
-        if self.cut is not None:
-            self.model.object_model.grad_cut = self.cut if on else None
+        if self.cuts:
+            self.model.object_model.grad_cut = self.cuts if on else None
+
+    # ---- the step as a list of pieces: piece 0 = forward + losses + the top of the backward, piece k = the next stretch of it --------
+    def _piece(self, k, data):
+        last = k == len(self.cuts)
+        if k == 0:
+            self.opt.zero_grad()
+            if not self.collective:
+                self.opt.begin_overlapped()
+            self._set_cut()
+            try:
+                self.out = backward_first(self.model, self.loss_fn, data)
+            except BaseException:
+                self.opt.abort_overlapped()
+                raise
+            finally:
+                self._set_cut(False)
+            self.opt._adopt_stray_grads()
+        else:
+            backward_next(self.model)
+        if last:
+            finish_backward(self.model)
+            self.opt.prepare()
+            if not self.collective:
+                self.opt.launch(grad_scale=1.0)
+
+    def _exchange_and_update(self, runs):
+        """All-reduce the given arena ranges of the gradient buffer (sum) and update the parameters of each reduced piece: collectives
+        queue on the communication stream behind what the current stream holds so far, each fused-AdamW range launch waits (on the
+        optimizer stream) for just its own piece."""
+        a = self.opt.arena
+        g = a.flat_g
+        pieces = list(self._pieces(runs))
+        if not pieces:
+            return
+        if not g.is_cuda:
+            for lo, hi in pieces:
+                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=g.device)
+            self._optst = torch.cuda.Stream(device=g.device)
+        self._comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            handles = [dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in pieces]
+        with torch.cuda.stream(self._optst):
+            for h, (lo, hi) in zip(handles, pieces):
+                h.wait()                                      # this stream waits for that collective only
+                ops.adamw_range_dev(a.flat_p, g, self.opt.m, self.opt.v, self.opt._hyper, a.flat_s, lo, hi)
+
+    def _begin_updates(self):
+        """Per step, before the first range update: hyper-parameters to the device if they changed, the device step counter advanced --
+        on the optimizer stream, behind the previous step's last update."""
+        self.opt._sync_hyper(1.0 / self.world)
+        if self._optst is None:
+            dev = self.opt.arena.flat_g.device
+            self._comm, self._optst = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self._optst.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._optst):
+            ops.adamw_prep_dev(self.opt._hyper)
+
+    def _end_updates(self):
+        torch.cuda.current_stream().wait_stream(self._optst)   # the next forward reads the updated weights (and their bf16 shadows)
+        self.opt.step_count += 1
+        self.opt._hyper_step = self.opt.step_count
+        if self.opt.arena.flat_s is not None:
+            self.opt.arena.adopt_shadow()
+        else:
+            Fn.SHADOWS.invalidate()
+
+    def _run_pieces(self, data, graphs=None):
+        n = len(self.cuts) + 1
+        if self.collective and self.opt.arena.flat_g.is_cuda:
+            self._begin_updates()
+        for k in range(n):
+            if graphs is not None:
+                graphs[k].replay()
+            else:
+                self._piece(k, data)
+            if self.collective:
+                self._exchange_and_update(self.piece_runs[k])
+        if self.collective:
+            if self.opt.arena.flat_g.is_cuda:
+                self._end_updates()
+            else:
+                self.opt.launch(grad_scale=1.0 / self.world)
 
     def _eager(self, data):
-        self.opt.zero_grad()
-        if not self.collective:
-            self.opt.begin_overlapped()
-        self._set_cut()
-        try:
-            losses = backward_first(self.model, self.loss_fn, data)
-        except BaseException:
-            self.opt.abort_overlapped()
-            raise
-        finally:
-            self._set_cut(False)
-        handles = []
-        if self.cut is not None:
-            self.opt._adopt_stray_grads()
-            handles = self._exchange(self.early_runs, overlapped=True)
-        backward_second(self.model)
-        self.opt.prepare()
-        if self.collective:
-            self._exchange(self.late_runs)
-            for h in handles:
-                h.wait()
-        self.opt.launch(grad_scale=1.0 / self.world)
-        return losses
+        self._run_pieces(data)
+        return self.out
 
     def _capture(self, data):
         self.static = {"text": {k: v.clone() for k, v in data["text"].items()}, "object": data["object"].clone(),
                        "object_mask": data["object_mask"].clone()}
         self.shape_key = self._key(data)
         torch.cuda.synchronize()
-        self.graph, self.graph2 = torch.cuda.CUDAGraph(), None
         self.opt._sync_hyper(1.0 / self.world)              # no host->device copy may happen inside the capture
-        self._set_cut()
-        if self.cut is None:
-            with torch.cuda.graph(self.graph):
-                self.opt.zero_grad()
-                if not self.collective:
-                    self.opt.begin_overlapped()
-                self.out = forward_backward(self.model, self.loss_fn, self.static)
-                self.opt.prepare()
-                if not self.collective:
-                    self.opt.launch(grad_scale=1.0)
-            if not self.collective:
-                self.opt.step_count -= 1                      # launch() counted a step, but capturing executed nothing
-            return
-        # two graphs sharing one memory pool: the second consumes what the first saved (activations, the cut's gradient)
-        with torch.cuda.graph(self.graph):
-            self.opt.zero_grad()
-            self.out = backward_first(self.model, self.loss_fn, self.static)
-            self.opt._adopt_stray_grads()
-        self._set_cut(False)
-        self.graph2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
-            backward_second(self.model)
-            self.opt.prepare()
+        self.graphs = []
+        for k in range(len(self.cuts) + 1):                 # graphs sharing one memory pool: each consumes what the previous ones saved
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **({"pool": self.graphs[0].pool()} if self.graphs else {})):
+                self._piece(k, self.static)
+            self.graphs.append(g)
+        if not self.collective:
+            self.opt.step_count -= 1                          # launch() counted a step, but capturing executed nothing
 
     def __call__(self, data):
         self.calls += 1
-        if self.graph is None or self._key(data) != self.shape_key:
+        if self.graphs is None or self._key(data) != self.shape_key:
             if self.calls <= self.warmup:
                 return self._eager(data)
             self._capture(data)
@@ -639,19 +725,11 @@ class GraphedTrainStep:
             # the captured AdamW kernels read lr / betas / eps / wd / the step counter from the device buffer: follow any change the
             # host made since the last call (param_groups[0]['lr'] = ..., load_state_dict) -- outside the graph, copies only on change
             self.opt._sync_hyper(1.0)
-        self.graph.replay()
-        if not self.collective:
+            self.graphs[0].replay()
             self.opt.replayed()
-            return tuple(t.clone() for t in self.out)          # fresh tensors, like the eager step: a later replay must not rewrite them
-        handles = []
-        if self.graph2 is not None:
-            handles = self._exchange(self.early_runs, overlapped=True)     # travels while the second graph runs
-            self.graph2.replay()
-        self._exchange(self.late_runs)
-        for h in handles:
-            h.wait()
-        self.opt.launch(grad_scale=1.0 / self.world)
-        return tuple(t.clone() for t in self.out)
+        else:
+            self._run_pieces(None, self.graphs)
+        return tuple(t.clone() for t in self.out)            # fresh tensors, like the eager step: a later replay must not rewrite them
 
 
 def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False, log=None, precision=None):

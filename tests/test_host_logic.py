@@ -314,7 +314,7 @@ def test_two_graph_exchange_plan_covers_the_arena_once():
         offs.append(o)
         o += (z + 63) // 64 * 64
     arena = SimpleNamespace(names=names, offsets=offs, total=o, n_matrix=n_matrix, ALIGN=64, params=[SimpleNamespace(numel=lambda z=z: z) for z in sizes])
-    early, late = GraphedTrainStep.plan_exchange(arena, cut=2)
+    early, late = GraphedTrainStep.plan_exchange(arena, 2)
     assert len(early) == 2                                       # the text tower, and object blocks 2..3
     spans = sorted(list(early) + list(late))
     assert spans[0][0] == 0 and spans[-1][1] == arena.total
@@ -323,3 +323,15 @@ def test_two_graph_exchange_plan_covers_the_arena_once():
         inside = [n for n, off in zip(names, offs) if lo <= off < hi]
         assert inside and all(n.startswith("text_model.") or int(n.split(".")[2]) >= 2 for n in inside)
         assert all(names.index(n) < n_matrix for n in inside)
+    # several cuts: piece 0 = text tower + blocks >= 3, piece 1 = block 2, piece 2 = block 1, last = the rest (block 0, prologue, heads, vectors)
+    pieces = GraphedTrainStep.plan_exchange(arena, (3, 2, 1))
+    assert len(pieces) == 4 and all(pieces)
+    spans = sorted(r for runs in pieces for r in runs)
+    assert spans[0][0] == 0 and spans[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    want = [lambda n: n.startswith("text_model.") or int(n.split(".")[2]) >= 3, lambda n: n.split(".")[2] == "2", lambda n: n.split(".")[2] == "1"]
+    for k in range(3):
+        for lo, hi in pieces[k]:
+            inside = [n for n, off in zip(names, offs) if lo <= off < hi]
+            assert inside and all(want[k](n) for n in inside) and all(names.index(n) < n_matrix for n in inside)
+    last = [n for lo, hi in pieces[3] for n, off in zip(names, offs) if lo <= off < hi]
+    assert "object_model.blocks.0.attn.qkv.weight" in last and "txt_proj.1.weight" in last and "text_model.some.bias" in last

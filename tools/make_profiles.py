@@ -23,6 +23,18 @@ def one(pattern):
     return g[0] if g else None
 
 
+import subprocess
+try:
+    GIT_HEAD = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    if subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "demovlp_amd/csrc"], capture_output=True, text=True).stdout.strip():
+        GIT_HEAD = (GIT_HEAD or "?") + "+uncommitted-csrc"
+except Exception:
+    GIT_HEAD = None
+try:
+    CSRC_SHA = open(os.path.join(SRC, "csrc_sha.txt")).read().strip()         # hashed on the GPU box, of the tree that was profiled
+except Exception:
+    CSRC_SHA = None
+PROV = {"git_head": GIT_HEAD, "csrc_sha": CSRC_SHA}
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(P, tag + "_bench.json"), "w").write(line)
 st = one("trace/**/*kernel_stats.csv")
@@ -60,7 +72,7 @@ if fc and wc:
                      "--warmup 1 --no-kernel-timing --no-cpu-baseline, MI355X (tools/profile_round.sh)",
            "note": "KiB of L2<->fabric traffic (Infinity-Cache hits included); reads doubled per MI355X_MICROARCH.md (HBM section); the split-K "
                    "slab reductions are charged to the GEMM launch they belong to",
-           "gemm_launches": fn, "fetch_size_kib_per_launch": fs / fn, "write_size_kib_per_launch": ws / wn,
+           **PROV, "gemm_launches": fn, "fetch_size_kib_per_launch": fs / fn, "write_size_kib_per_launch": ws / wn,
            "gemm_family_traffic_bytes_per_launch": traffic}
     json.dump(out, open(os.path.join(P, tag + "_gemm_hbm_traffic_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
@@ -83,7 +95,7 @@ if mc:
                    "rocprofv3 reports summed over the 8 XCDs, brought back to one clock (cross-check: p8 kernels 0.30 busy ~ 750 TFLOP/s of 2500; ROCm 7.2 ships no gfx950 "
                    "derived-counter section); lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES "
                    "(share of wave time at s_waitcnt / barriers); mfma_ops_bf16 are 512-FLOP units per MI355X_MICROARCH.md",
-           "families": {}}
+           **PROV, "families": {}}
     for f, c in agg.items():
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         out["families"][f] = {"launches": cnt[f],
@@ -114,9 +126,15 @@ if fc and wc:
               "write_mb_per_launch": round(wa.get(k, 0.0) * 1024 / fn_[k] / 1e6, 1), "share_of_all_traffic": round(t / total, 4)} for t, k in rows[:25]]
     json.dump({"source": "the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh (KiB counters; reads doubled per MI355X_MICROARCH.md); L2<->fabric, "
                          "Infinity-Cache hits included, so HBM traffic proper is lower for operands that stay in the 256 MB MALL",
-               "kernels": table}, open(os.path.join(P, tag + "_traffic_by_kernel.json"), "w"), indent=1)
+               **PROV, "kernels": table}, open(os.path.join(P, tag + "_traffic_by_kernel.json"), "w"), indent=1)
 
-for extra in ("select_bench.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt"):
+f32 = os.path.join(SRC, "bench_f32_b16.json")
+if os.path.exists(f32):
+    l32 = [l for l in open(f32) if l.startswith("{")]
+    if l32:
+        open(os.path.join(P, tag + "_bench_f32_b16.json"), "w").write(l32[-1])
+for extra in ("select_bench.txt", "select_bench_f32.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt",
+              "input_bench.txt", "eval_bench.txt", "tile_height_bench.txt", "attn_bench.txt"):
     src = os.path.join(SRC, extra)
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]

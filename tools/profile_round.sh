@@ -7,6 +7,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_round
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# which kernels these counters belong to (bench.py reports `traffic` only for a tree whose csrc hashes to the same value)
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc_sha())" > $O/csrc_sha.txt
 timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/fetch.err
@@ -21,6 +23,13 @@ timeout 300 python3 $R/tools/xloss_bench.py > $O/xloss_bench.txt 2>&1
 timeout 300 python3 $R/tools/epi_bench.py > $O/epi_bench.txt 2>&1
 timeout 300 python3 $R/tools/lib_gemm_ref.py > $O/lib_gemm_ref.txt 2>&1
 DVLP_PROF_REPORT=1 timeout 300 python3 $R/bench.py --no-cpu-baseline --no-object-tower --steps 10 --warmup 3 2>&1 | grep "kern=" | sort > $O/gemm_shapes.txt
+# config 5 (32-frame long-video variant, B = 16 per GPU): one bench line and K1 at F = 32; the input side (host staging + PCIe + select)
+timeout 600 python3 $R/bench.py --frames 32 --batch 16 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_f32_b16.json 2> $O/bench_f32.err
+SELECT_F=32 SELECT_B=16 timeout 300 python3 $R/tools/select_bench.py > $O/select_bench_f32.txt 2>&1
+timeout 300 python3 $R/tools/input_bench.py > $O/input_bench.txt 2>&1
+timeout 900 python3 $R/tools/eval_bench.py --pairs 1000 > $O/eval_bench.txt 2>&1
+timeout 300 python3 $R/tools/tile_height_bench.py > $O/tile_height_bench.txt 2>&1
+timeout 300 python3 $R/tools/attn_bench.py > $O/attn_bench.txt 2>&1
 # keep what travels back small: the per-dispatch traces are large
 for d in trace fetch write mfma; do find $O/$d -name "*kernel_trace.csv" -size +20M -delete; done
 ls -la $O $O/trace $O/fetch $O/write $O/mfma

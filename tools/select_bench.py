@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from demovlp_amd import ops, synthetic as syn  # noqa: E402
 
 dev = "cuda"
-B, F, R = 64, 8, 36
+B, F, R = int(os.environ.get("SELECT_B", "64")), int(os.environ.get("SELECT_F", "8")), 36      # SELECT_F=32 SELECT_B=16: BASELINE config 5
 for Nraw in (36, 50, 100):
     g = torch.Generator(device=dev).manual_seed(Nraw)
     feats = torch.rand(B, F, Nraw, 2048, device=dev, generator=g)
