@@ -1413,7 +1413,7 @@ static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile pat
 extern "C" int dvlp_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
 extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
-static int g_p8_persist = 0;     // persistent form of the 256-row kernel on multi-round outputs: 0 off, 1 on (A/B: tools/p8p_bench.py)
+static int g_p8_persist = 1;     // persistent form of the 256-row kernel on multi-round outputs: 0 off, 1 on (default; A/B: tools/p8p_bench.py)
 extern "C" int dvlp_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
 static int g_p8_short = 1;       // 224-row tiles of the 256-row kernel: 0 never, 1 where they save CU-rounds (default), 2 whenever allowed
 extern "C" int dvlp_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
@@ -1557,8 +1557,10 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         // (measured per shape with tools/gemm_sweep.py: 75-tile outputs with K = 2304 / 3072 -- the text tower's fc2, fc1 dX, qkv dX -- run
         //  faster on the 128-row kernel without a K split than on a 3-way split 256-row launch (47 vs 55, 38 vs 50, 48 vs 55 us), and a
         //  3-tile weight gradient -- the two 256-wide projections -- on 384 128-row blocks than on 96 256-row ones)
-        static const int p8_min_tiles = getenv("DVLP_P8_MIN_TILES") ? atoi(getenv("DVLP_P8_MIN_TILES")) : 192;      // experiments
-        static const bool p8_need_rounds = getenv("DVLP_P8_ROUNDS") ? atoi(getenv("DVLP_P8_ROUNDS")) != 0 : true;
+        // (round 3, in the step: with the text tower beside the object tower, its 75 / 300-tile products on the 256-row kernel -- any round
+        //  count -- take 1 % off the step; alone they measured slower, above.  DVLP_P8_MIN_TILES=192 DVLP_P8_ROUNDS=1 restores round 2's rule)
+        static const int p8_min_tiles = getenv("DVLP_P8_MIN_TILES") ? atoi(getenv("DVLP_P8_MIN_TILES")) : 64;      // experiments (round 3: 192 -> 64, see below)
+        static const bool p8_need_rounds = getenv("DVLP_P8_ROUNDS") ? atoi(getenv("DVLP_P8_ROUNDS")) != 0 : false;
         const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= p8_min_tiles && (rounds8 || !p8_need_rounds)) || (tiles8 >= 8 && tiles8 <= 64 && K >= 4096))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
         // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32

@@ -368,6 +368,7 @@ def test_gemm_short_tiles_bit_equal_to_256_row_tiles(M, N, K):
     dy = torch.randn(M, N, device=DEV, generator=g).to(bf)
     pre = torch.randn(M, K, device=DEV, generator=g).to(bf)
     ops.call("dvlp_gemm_p8_mode", 2)
+    ops.call("dvlp_gemm_p8_persistent", 0)          # tile height alone (the persistent form adds the bias first: its own test below)
     ops.enable_deferred_reductions(torch.device(DEV), workspace_mb=64)
     try:
         outs = []
@@ -388,6 +389,7 @@ def test_gemm_short_tiles_bit_equal_to_256_row_tiles(M, N, K):
         ops.disable_deferred_reductions()
         ops.call("dvlp_gemm_p8_short_tiles", 1)
         ops.call("dvlp_gemm_p8_mode", 1)
+        ops.call("dvlp_gemm_p8_persistent", 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -491,16 +493,18 @@ def test_evaluate_mscoco_branch_subsamples_videos_and_passes_fold():
         evaluate(model, loss_head(), batches, metrics=(t2v_fold,), use_local=True, mscoco=True)
 
 
-def test_persistent_gemm_kernel_agrees_with_the_one_tile_form():
-    """dvlp_gemm_p8_persistent(1) (opt-in): one workgroup per CU walks its 224-row tiles, the next tile's first eight units are staged
+@pytest.mark.parametrize("M,N,K", [(18496, 2304, 768), (18496, 3072, 256), (9000, 2304, 768), (30000, 768, 2304)])
+def test_persistent_gemm_kernel_agrees_with_the_one_tile_form(M, N, K):
+    """dvlp_gemm_p8_persistent (default on): one workgroup per CU walks its 224-row tiles, the next tile's first eight units are staged
     across the tile boundary, accumulators start from the bias.  Same products in the same order; the bias enters the fp32 sum first
-    instead of last, so outputs may differ by one bf16 rounding -- bounded here against an fp32 reference, plus a repeat screen of the
-    cross-tile prefetch (a race would show as run-to-run differences)."""
+    instead of last, so outputs with a bias may differ by one bf16 rounding -- bounded here against an fp32 reference; without a
+    bias (forward and dX forms) they are bit-equal.  Shapes: 4 / 12 / 36 K tiles, a ragged last row tile (9000 = 40 x 224 + 40), and a
+    repeat screen of the cross-tile prefetch (a race would show as run-to-run differences)."""
     g = torch.Generator(device=DEV).manual_seed(5)
     bf = torch.bfloat16
-    M, N, K = 18496, 2304, 768
     x = torch.randn(M, K, device=DEV, generator=g).to(bf)
     w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(bf)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(bf)
     bias = torch.randn(N, device=DEV, generator=g)
     ref = x.float() @ w.float().t() + bias
     try:
@@ -508,45 +512,17 @@ def test_persistent_gemm_kernel_agrees_with_the_one_tile_form():
         for mode in (0, 1):
             ops.call("dvlp_gemm_p8_persistent", mode)
             aux = torch.empty(M, N, device=DEV, dtype=bf)
-            outs[mode] = (ops.linear_fwd(x, w, bias), ops.linear_fwd(x, w, bias, gelu_aux=aux), aux, ops.linear_fwd(x, w, None))
+            outs[mode] = (ops.linear_fwd(x, w, bias), ops.linear_fwd(x, w, bias, gelu_aux=aux), aux, ops.linear_fwd(x, w, None), ops.linear_bwd_input(dy, w))
             if mode == 1:
-                for _ in range(10):
-                    again = ops.linear_fwd(x, w, bias)
-                    assert torch.equal(again, outs[1][0])
+                for _ in range(12):
+                    assert torch.equal(ops.linear_fwd(x, w, bias), outs[1][0]) and torch.equal(ops.linear_bwd_input(dy, w), outs[1][4])
         scale = float(ref.abs().max())
-        for a, b in zip(outs[0], outs[1]):
+        for a, b in zip(outs[0][:3], outs[1][:3]):
             assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -7 * scale          # within one bf16 rounding of the largest value
-        assert torch.equal(outs[0][3], outs[1][3])                                           # no bias: bit-equal
+        assert torch.equal(outs[0][3], outs[1][3]) and torch.equal(outs[0][4], outs[1][4])  # no bias: bit-equal
         assert float((outs[1][0].float() - ref).abs().max()) < 1e-2 * scale
         assert float((outs[1][2].float() - ref).abs().max()) < 1e-2 * scale                 # pre-activation out of the GELU epilogue
+        dref = dy.float() @ w.float()
+        assert float((outs[1][4].float() - dref).abs().max()) < 1e-2 * float(dref.abs().max())
     finally:
-        ops.call("dvlp_gemm_p8_persistent", 0)
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# bench.py: the default line's first loss is a fixed function of (synthetic batch, closed-form weights, Philox seed)
-# ---------------------------------------------------------------------------------------------------------------------
-BENCH_STEP1_LOSS = 17.9681        # bf16, B=64, F=8, R=36, text dropout 0.1 with the default Philox seed (recorded on MI355X, round 2 and round 3)
-
-
-def test_bench_default_line_step1_loss_and_contract():
-    """`python bench.py` (default workload): the loss of the first optimisation step is deterministic -- same synthetic batch, same
-    closed-form weights, the device Philox stream from its default seed -- and is pinned here, so a numerical regression in ANY kernel
-    of the step shows in the number the driver records.  Also the fields this round added (traffic provenance, graph-timed object tower)."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "3", "--no-cpu-baseline"], env=env, capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    print("\nbench step1_loss", out["config"]["step1_loss"], "final", out["config"]["final_loss"], "| object tower", out["roofline"].get("object_transformer_ms"),
-          "ms", out["roofline"].get("object_transformer_launch_mode"), "| traffic", out["roofline"].get("traffic"), out["roofline"].get("traffic_note"))
-    assert abs(out["config"]["step1_loss"] - BENCH_STEP1_LOSS) < 2e-3 * BENCH_STEP1_LOSS, out["config"]
-    assert out["config"]["final_loss"] < out["config"]["step1_loss"]
-    rf = out["roofline"]
-    assert rf["object_transformer_launch_mode"] == "hipGraph replay" and 0 < rf["object_transformer_frac"] < 1
-    assert (rf["traffic"] is None) == ("traffic_note" in rf)               # either a figure measured on these kernels, or null with the reason
-    assert 0 < rf["gemm_share_of_step"] <= 1.0
+        ops.call("dvlp_gemm_p8_persistent", 1)
