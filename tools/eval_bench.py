@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Retrieval evaluation at MSRVTT test-set size (BASELINE.json configs[3] shape: F=8, R=30, 1000 video-caption pairs, batch 32)
-through trainer.evaluate(): tower forwards, global sim_matrix [1000 x 1000], the local grid over all 10^6 pairs on the fused
-per-pair kernel, the reference's addend orientation, R@1/5/10/50 / MedR / MeanR both ways.  Weights are the closed-form synthetic
+through trainer.evaluate(): tower forwards, global sim_matrix [1000 x 1000], the local grid over all 10^6 pairs (bf16 model: the fused
+per-pair kernel; --dtype float32: the fp32 multi-kernel parity path), the reference's addend orientation, R@1/5/10/50 / MedR / MeanR both ways.  Weights are the closed-form synthetic
 fill, so the metrics are chance-level; what this measures is the wall time of the path (the reference walks the grid in 8 x 8
 tiles from a Python loop, model/loss.py:73-103: 15 625 calls)."""
 import argparse
