@@ -30,7 +30,7 @@ def _parse_header(path=HEADER_PATH):
     for m in re.finditer(r"\b(int64_t|int)\s+(dvlp_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argtypes = []
-        for a in [x.strip() for x in args.split(",") if x.strip()]:
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
             if "*" in a:
                 argtypes.append(ctypes.c_void_p)
             else:

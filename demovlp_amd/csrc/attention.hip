@@ -46,6 +46,9 @@ struct AttnArgs {
     float *cls_o, *cls_st, *cls_stats, *dq_ws;
     const void* fwd_out;
     int64_t ld_fo;
+    // merged backward: partial column sums of dq | dk | dv as stored (the gradient of the packed qkv bias): [B*F + B][3*H*64] fp32, one row
+    // per (b, frame) written by that frame's 12 head waves + one row per b for the CLS token's rows; summed by the deferred-reduction queue
+    float* csum;
 };
 static thread_local const uint8_t *t_keep = nullptr, *t_keepT = nullptr;
 static thread_local float t_kscale = 1.f;
@@ -510,6 +513,28 @@ __device__ __forceinline__ void emit_rows(bf16* Ts, const f32x4 (&acc)[NT][4], f
     }
 }
 
+// column sums (64 channels of head h) of the rows emit_rows just wrote from the wave's LDS tile -- the bf16 values as stored -- into dst[64]
+template <int NT>
+__device__ __forceinline__ void tile_colsum(const bf16* Ts, const Seg& sg, bool keys, int lane, float* __restrict__ dst) {
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NT * 2; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const int tok = keys ? (row == 0 ? -1 : sg.tok_k(row)) : sg.tok_q(row);
+        if (tok >= 0) {
+            const bf16x8 v = *(const bf16x8*)&Ts[row * VLD + ch * 8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a8[e] = stride8_sum(a8[e]);
+    if ((lane >> 3) == 0) {
+        *(float4*)(dst + 8 * lane) = make_float4(a8[0], a8[1], a8[2], a8[3]);
+        *(float4*)(dst + 8 * lane + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     bf16x8 r;
     r[0] = (bf16)a[0]; r[1] = (bf16)a[1]; r[2] = (bf16)a[2]; r[3] = (bf16)a[3];
@@ -936,6 +961,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[0][dt][0] * mul;
         }
         emit_rows<NT>(Ts, acc, mul, dst, brow0, a.ldd, h, sg, true, lane);
+        if (a.csum) tile_colsum<NT>(Ts, sg, true, lane, a.csum + ((int64_t)b * a.F + sg.f) * (3 * a.H * HD) + (pass == 0 ? 2 : 1) * a.H * HD + h * HD);
     }
     // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: K through the tile (transposing read, natural key order), then dS
     {               // K again from global (L2-warm), for the same reason
@@ -981,6 +1007,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 }
     }
     emit_rows<NT>(Ts, dqa, a.scale, dq, brow0, a.ldd, h, sgp, false, lane);
+    if (a.csum) tile_colsum<NT>(Ts, sgp, false, lane, a.csum + ((int64_t)b * a.F + sgp.f) * (3 * a.H * HD) + h * HD);
 }
 
 // launch A of the merged backward: CLS-query statistics and dq_cls.  stats[b][h] = (max, sum, D, -)
@@ -1069,11 +1096,15 @@ __global__ __launch_bounds__(64) void attn_bwd_cls_post_kernel(AttnArgs a) {
     const int64_t off = (int64_t)b * a.N * a.ldd + h * HD + lane;
     ((T*)a.dk)[off] = from_f<T>(gk);
     ((T*)a.dv)[off] = from_f<T>(gv);
+    float gq = 0.f;
     if (a.dq_ws) {
         const float* wq = a.dq_ws + (((int64_t)b * a.H + h) * a.F) * HD;
-        float gq = 0.f;
         for (int f = 0; f < a.F; ++f) gq += wq[f * HD + lane];
         ((T*)a.dq)[off] = from_f<T>(gq);
+    }
+    if (a.csum) {        // the CLS token's rows of dq | dk | dv (as stored): partial row B*F + b
+        float* cr = a.csum + ((int64_t)a.B * a.F + b) * (3 * a.H * HD) + h * HD + lane;
+        cr[0] = to_f(from_f<T>(gq)); cr[a.H * HD] = to_f(from_f<T>(gk)); cr[2 * a.H * HD] = to_f(from_f<T>(gv));
     }
 }
 
@@ -1277,6 +1308,14 @@ static int attn_check(const AttnArgs& a) {
     return DVLP_OK;
 }
 
+float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out);      // norm.hip: deferred-reduction queue
+static thread_local float* t_attn_csum_next = nullptr;
+static thread_local int t_attn_csum_fused = 0;
+// the NEXT dvlp_attention_bwd (mode 0) of this host thread also queues the column sums of dq | dk | dv ([3*H*64] fp32: the packed qkv bias
+// gradient) into `dst` when it can (bf16 one-pass form with forward statistics, deferred reductions enabled); dvlp_attention_bwd_colsum_fused()
+// says whether the last call did -- if not, the caller runs its own column-sum pass
+extern "C" int dvlp_attention_bwd_colsum_next(float* dst) { t_attn_csum_next = dst; return DVLP_OK; }
+extern "C" int dvlp_attention_bwd_colsum_fused() { return t_attn_csum_fused; }
 static int g_attn_fold = 1;        // space-mode bf16: 1 = CLS query folded into the frame waves when the caller passes workspaces, 0 = separate launches (A/B, tests)
 extern "C" int dvlp_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
 
@@ -1352,6 +1391,8 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
     a.keep = mode == 1 ? t_keep : nullptr; a.keepT = mode == 1 ? t_keepT : nullptr; a.kscale = t_kscale; a.Ns = (int)((N + 15) / 16 * 16);
     t_keep = nullptr; t_keepT = nullptr; t_kscale = 1.f;
+    float* const csum_dst = t_attn_csum_next;
+    t_attn_csum_next = nullptr; t_attn_csum_fused = 0;
     if (int rc = attn_check(a)) return rc;
     if (mode == 0 && !workspace) return DVLP_ERR_SHAPE;
     const int nseg = mode == 0 ? (int)F : 1, nk = (int)R + (mode == 0 ? 1 : 0);
@@ -1376,6 +1417,10 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
             if (fwd_out && cls_stats && g_attn_fold) {      // statistics from the folded forward: no statistics pass, dq_cls from per-frame partials
                 stats = const_cast<float*>(cls_stats);
                 a.fwd_out = fwd_out; a.ld_fo = ld_fwd_out; a.dq_ws = workspace + B * H * F * 2 * HD + B * H * 4;
+                if (csum_dst) {      // the CLS rows reach the partial buffer through the closing launch, which needs dq_cls: this form only
+                    a.csum = dvlp_rd_reserve_push(B * F + B, 3 * H * HD, csum_dst);
+                    t_attn_csum_fused = a.csum != nullptr;
+                }
             } else hipLaunchKernelGGL(attn_bwd_cls_pre_kernel<bf16>, grid2, block, lds2, st, a, stats);
 #define MMRG(NT_) hipLaunchKernelGGL((mattn_bwd_space_merged_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, \
                                      (size_t)4 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16), st, a, items, (const float*)stats)

@@ -132,6 +132,7 @@ def _early_update(params):
 FUSE_TEXT_QKV = os.environ.get("DVLP_NO_FUSED_QKV") is None      # developer switch for A/B timing
 FUSE_LN_COLSUM = os.environ.get("DVLP_NO_LN_COLSUM") is None     # developer switch for A/B timing
 FUSE_GEMM_COLSUM = os.environ.get("DVLP_NO_GEMM_COLSUM") is None  # developer switch for A/B timing
+FUSE_ATTN_COLSUM = os.environ.get("DVLP_NO_ATTN_COLSUM") is None  # developer switch for A/B timing
 
 
 def _stacked(ts):
@@ -324,8 +325,13 @@ class VitBlockFn(torch.autograd.Function):
         dh2 = ops.linear_bwd_input(dpre, SHADOWS.get(f1w, cd))
         dx1, dn2w, dn2b, dpb = _ln_bwd(dh2, x1, n2w, n2b, m2, r2, dres=dy2, bias_of_next=pb)
         datt = ops.linear_bwd_input(dx1, SHADOWS.get(pw, cd))
-        dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R, out=att, stats=cls_stats)
-        dqkvb = _bgrad(dqkv, qkvb)
+        gqb = _grad_buf(qkvb)
+        if gqb is not None and FUSE_ATTN_COLSUM:       # qkv-bias gradient = column sums of dqkv: queued from inside the attention backward
+            dqkv, fused = ops.space_attention_bwd(qkv, addmask, datt, B, F, R, out=att, stats=cls_stats, colsum_to=gqb)
+            dqkvb = gqb if fused else _bgrad(dqkv, qkvb)
+        else:
+            dqkv = ops.space_attention_bwd(qkv, addmask, datt, B, F, R, out=att, stats=cls_stats)
+            dqkvb = _bgrad(dqkv, qkvb)
         dh1 = ops.linear_bwd_input(dqkv, SHADOWS.get(qkvw, cd))
         # the four weight gradients of the block (9-36 output tiles each, K = B*N tokens) as ONE grouped GEMM
         df2w, df1w, dpw, dqkvw = _wgrad_group([(dy2, a, f2w), (dpre, h2, f1w), (dx1, att, pw), (dqkv, h1, qkvw)])

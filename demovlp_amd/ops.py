@@ -290,8 +290,10 @@ def space_attention_fwd(qkv, addmask, B, F, R, want_stats=False):
     return (out, stats) if want_stats else out
 
 
-def space_attention_bwd(qkv, addmask, dout, B, F, R, out=None, stats=None):
-    """``out`` / ``stats``: the forward's output and the statistics it returned (``want_stats``), or None."""
+def space_attention_bwd(qkv, addmask, dout, B, F, R, out=None, stats=None, colsum_to=None):
+    """``out`` / ``stats``: the forward's output and the statistics it returned (``want_stats``), or None.  ``colsum_to``: fp32 [2304]
+    destination of the column sums of dqkv (the packed qkv bias gradient), queued from inside the kernels when possible (final after
+    :func:`flush_reductions`); returns (dqkv, fused) then -- ``fused`` False means the caller still has to sum the columns."""
     N = 1 + F * R
     dqkv = torch.empty_like(qkv)
     es = qkv.element_size()
@@ -299,9 +301,13 @@ def space_attention_bwd(qkv, addmask, dout, B, F, R, out=None, stats=None):
     ws = _workspace("attn", B * HEADS * (F * 3 * 64 + 4), qkv.device)
     if stats is None:
         out = None
+    if colsum_to is not None:
+        call("dvlp_attention_bwd_colsum_next", p(colsum_to))
     call("dvlp_attention_bwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(b), ctypes.c_void_p(b + 768 * es),
          ctypes.c_void_p(b + 1536 * es), 2304, p(addmask), p(dout), 768, ctypes.c_void_p(db), ctypes.c_void_p(db + 768 * es),
          ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, p(out), 768, p(stats), stream())
+    if colsum_to is not None:
+        return dqkv, bool(_lib.load().dvlp_attention_bwd_colsum_fused())
     return dqkv
 
 

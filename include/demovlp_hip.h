@@ -131,6 +131,11 @@ int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int
                        void* stream);
 /* 1 (default): fold the CLS query where workspaces are given; 0: separate CLS launches -- for A/B measurements and tests */
 int dvlp_attention_cls_fold(int on);
+/* the NEXT dvlp_attention_bwd (mode 0) issued by this host thread also queues the column sums of dq | dk | dv (fp32 [3*H*64]: the gradient
+   of the packed qkv bias, object_transformer.py:310 qkv_bias=True) into `dst` through the deferred-reduction queue when it can (bf16 one-pass
+   form with the forward's statistics); dvlp_attention_bwd_colsum_fused() = 1 if the last call did, else the caller sums the columns itself */
+int dvlp_attention_bwd_colsum_next(float* dst);
+int dvlp_attention_bwd_colsum_fused(void);
 
 /* ---- tower prologues: ObjectTransformer.forward_features (object_transformer.py:400-433); DistilBERT embeddings ---- */
 int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* box, void* stream);
