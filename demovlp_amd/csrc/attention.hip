@@ -542,8 +542,10 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     return r;
 }
 
+// (space mode, NKT <= 3: four waves per SIMD -- 116 registers without spilling against 139 at the compiler's own choice of three; the kernel is
+//  one load -> compute -> store pass per wave, so resident waves are what hides its memory latency.  The 7 / 8-tile text form would spill.)
 template <int NQT, int NKT>
-__global__ __launch_bounds__(256) void mattn_fwd_kernel(AttnArgs a, int items, int qgroups) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NKT <= 3 ? 4 : 2))) void mattn_fwd_kernel(AttnArgs a, int items, int qgroups) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     constexpr int NKTP = (NKT + 1) & ~1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;

@@ -862,9 +862,15 @@ __device__ __attribute__((noinline)) void p8_store_ragged(const Epi& e, bf16* __
 #ifdef DVLP_STAMP
 __device__ unsigned long long* g_p8_stamp = nullptr;
 extern "C" int dvlp_p8_stamp_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_p8_stamp), &p, sizeof p) == hipSuccess ? DVLP_OK : DVLP_ERR_LAUNCH; }
-#define P8_STAMP(i) do { st[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define P8_STAMP(i) do { if (st) st[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per-phase shader-clock stamps inside the K loop (issued where they are taken, consumed at the end of the phase so that no extra wait lands
+// between the fragment reads and the barrier): where a phase spends its time -- load segment, first barrier, MFMA cluster, second barrier
+#define P8_PH(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define P8_PH_ACC(q) do { if (st) { st[8 + 4 * (q)] += ph1 - ph0; st[9 + 4 * (q)] += ph2 - ph1; st[10 + 4 * (q)] += ph3 - ph2; st[11 + 4 * (q)] += ph4 - ph3; } } while (0)
 #else
 #define P8_STAMP(i) do { } while (0)
+#define P8_PH(v) do { } while (0)
+#define P8_PH_ACC(q) do { } while (0)
 #endif
 struct P8Stamps { unsigned long long t[5]; };
 
@@ -1052,6 +1058,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     // operations may sit in the queue), 2 = middle, 3 = last (switches to the next tile's units at phase U - 6 = (q 2, parity 0))
     auto phase = [&](auto q_, auto par_, auto var_, int P) {
         constexpr int Q = decltype(q_)::value, PAR = decltype(par_)::value, VAR = decltype(var_)::value;
+        P8_PH(ph0);
         // ---- load segment: fragment reads of this phase, one unit of prefetch, counted wait for what the NEXT phase reads
         if constexpr (Q == 0) { read_b(par_, I1{}, bL, bllo, blhi); read_a(par_, I0{}); }
         if constexpr (Q == 1) read_b(par_, I2{}, bH, bhlo, bhhi);
@@ -1070,7 +1077,9 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
                 else p_vmcnt<8>();
             }
         }
+        P8_PH(ph1);
         __builtin_amdgcn_s_barrier();
+        P8_PH(ph2);
         // ---- MFMA segment
         if constexpr (Q == 0) { land_b(bL, bllo, blhi); land_a(); }
         if constexpr (Q == 1) land_b(bH, bhlo, bhhi);
@@ -1085,7 +1094,10 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
                 for (int j = 0; j < 2; ++j)
                     acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((NJ ? bH : bL)[s][j], aF[s][i], acc[MI + i][NJ + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        P8_PH(ph3);
         __builtin_amdgcn_s_barrier();
+        P8_PH(ph4);
+        P8_PH_ACC(Q);
     };
     auto pair = [&](auto var_, int t) {
         phase(I0{}, I0{}, var_, 4 * t + 0); phase(I1{}, I0{}, var_, 4 * t + 1); phase(I2{}, I0{}, var_, 4 * t + 2); phase(I3{}, I0{}, var_, 4 * t + 3);
@@ -1244,7 +1256,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
                                                            Epi e, int64_t ntn, int64_t kchunk, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 #ifdef DVLP_STAMP
-    unsigned long long st[5];
+    unsigned long long st[24] = {};
     P8_STAMP(0);
 #endif
     const int wg = xcd_remap32((int)blockIdx.x, (int)gridDim.x);
@@ -1260,13 +1272,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(int64_t M, int64_t N,
     P8_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P8_STAMP(4);
-    if (g_p8_stamp && threadIdx.x == 0) {
+    if (g_p8_stamp && (threadIdx.x == 0 || threadIdx.x == 256)) {        // one wave of each wave group (wr = 0, 1)
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* o = g_p8_stamp + 8 * (size_t)blockIdx.x;
+        unsigned long long* o = g_p8_stamp + 48 * (size_t)blockIdx.x + (threadIdx.x ? 24 : 0);
         o[0] = blockIdx.x; o[1] = hw; o[2] = xcc;
         for (int i = 0; i < 5; ++i) o[3 + i] = st[i];
+        for (int i = 8; i < 24; ++i) o[i] = st[i];
     }
 #else
     p8_tile<A_R, B_R, EK, MIH>(smem_raw, M, N, A, lda, B, ldb, C, ldc, e, (int64_t)tm_ * p8_tile_rows<MIH>(), (int64_t)tn_ * 256, kbeg, (int)((kend - kbeg) / H_BK), slab_out);

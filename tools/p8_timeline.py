@@ -32,6 +32,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_
 g = torch.Generator(device=dev).manual_seed(0)
 M0 = 18496
 lib.dvlp_gemm_p8_mode(2)                    # also for grids the dispatch would give to the 128-row kernel
+lib.dvlp_gemm_p8_persistent(0)              # the stamps live in the one-tile-per-workgroup kernel
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 shapes = [("qkv fwd (bias)", M0, 2304, 768, 0, 0, "b"), ("proj fwd (bias+res)", M0, 768, 768, 0, 0, "br"), ("fc1 fwd (gelu, aux out)", M0, 3072, 768, 0, 1, "ba"),
           ("fc2 dX (gelu', aux in)", M0, 3072, 768, 1, 2, "a"), ("fc2 fwd (bias+res) K=3072", M0, 768, 3072, 0, 0, "br"),
@@ -47,7 +48,7 @@ for label, M, N, K, tb, flags, ops_ in shapes:
     res = torch.randn(M, N, device=dev, generator=g).bfloat16() if "r" in ops_ else None
     aux = torch.randn(M, N, device=dev, generator=g).bfloat16() if "a" in ops_ else None
     ntile = ((M + 255) // 256) * ((N + 255) // 256)
-    buf = torch.zeros(ntile * 8, device=dev, dtype=torch.int64)
+    buf = torch.zeros(ntile * 48, device=dev, dtype=torch.int64)
 
     def run():
         rc = lib.dvlp_gemm(1, 0, tb, M, N, K, P(A), K, P(B), N if tb else K, P(C), N, P(bias), P(res), N if res is not None else 0, P(aux),
@@ -68,7 +69,8 @@ for label, M, N, K, tb, flags, ops_ in shapes:
     run()
     torch.cuda.synchronize()
     lib.dvlp_p8_stamp_buffer(ctypes.c_void_p(0))
-    r = buf.cpu().numpy().reshape(ntile, 8)
+    full = buf.cpu().numpy().reshape(ntile, 2, 24)
+    r = full[:, 0, :8]
     if not (r[:, 0] == np.arange(ntile)).all():
         print(f"\n=== {label}: not run on the 256-row kernel (no stamps) -- skipped")
         continue
@@ -96,5 +98,14 @@ for label, M, N, K, tb, flags, ops_ in shapes:
         print(f"    next entry - stores issued      : median {np.median(gaps3):6.2f}  p10 {np.percentile(gaps3, 10):6.2f}  p90 {np.percentile(gaps3, 90):6.2f} us")
     busy = (t[:, 2] - t[:, 1]).sum() / (ncu * span)
     print(f"    share of CU-time inside K loops: {busy:.3f}   (K-loop-only time would be {np.median(ph[:, 1]) * max(rounds):.1f} us)")
+    # inside the K loop: shader-clock cycles per phase kind q (0: reads B_lo + A_lo, 1: reads B_hi, 2: reads A_hi, 3: no reads), summed over the tile's K tiles
+    nkt = K // 64
+    for grp in (0, 1):
+        ph = full[:, grp, 8:24].reshape(ntile, 4, 4).astype(np.float64) / nkt
+        med = np.median(ph, axis=0)
+        tot = med.sum()
+        print(f"    K loop, wave group {grp} (cycles per K tile, median over tiles; total {tot:.0f}):")
+        for q in range(4):
+            print(f"        phase q{q}: load segment {med[q, 0]:6.0f}   first barrier {med[q, 1]:6.0f}   MFMA cluster (incl. fragment landing) {med[q, 2]:6.0f}   second barrier {med[q, 3]:6.0f}")
     last = np.sort(t[:, 4])
     print(f"    tail: 50 % of tiles done at {last[len(last) // 2]:.1f} us, 90 % at {last[int(len(last) * 0.9)]:.1f}, all at {last[-1]:.1f}")
