@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(256) void p8_group_reduce_kernel(P8GroupReduce g, i
     }
     *(float4*)(g.C[p] + i4) = s;
 }
-constexpr int P_LDS_TOTAL = P_EPI_LDS > P_LDS ? P_EPI_LDS : P_LDS;      // K-loop buffers / epilogue staging
+constexpr int P_LDS_TOTAL = (P_EPI_LDS > P_LDS ? P_EPI_LDS : P_LDS) + 8192;      // K-loop buffers / epilogue staging + 8 KiB of per-wave bias copies (persistent form)
 
 // second stage of a split-K GEMM: sum the S fp32 slabs of one output and apply the epilogue (8 columns per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int S, const float* __restrict__ slab, bf16* __restrict__ C,
@@ -1604,8 +1604,8 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         hipLaunchKernelGGL((gemm_bf16_p8_kernel<AR, BR, EK, MIH>), grid8, dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, ntn8, kchunk, slab); } while (0)
 #define LAUNCH_P8P_(AR, BR, EK, MIH) do { static bool once = false; if (!once) { once = true; \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8p_kernel<AR, BR, EK, MIH>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS + 8192); } \
-        hipLaunchKernelGGL((gemm_bf16_p8p_kernel<AR, BR, EK, MIH>), dim3((unsigned)ncu8), dim3(512), (size_t)(P_LDS + 8192), st, M, N, K, (const bf16*)A, lda, \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8p_kernel<AR, BR, EK, MIH>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } \
+        hipLaunchKernelGGL((gemm_bf16_p8p_kernel<AR, BR, EK, MIH>), dim3((unsigned)ncu8), dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, (int)ntm8h, (int)ntn8); } while (0)
 #define LAUNCH_P8S_(AR, BR, EK) do { if constexpr (!AR && (EK == 0 || EK == 2)) { if (p8p) { LAUNCH_P8P_(AR, BR, EK, 3); break; } } if constexpr (!AR) { \
         if (mih8 == 3) { LAUNCH_P8K_(AR, BR, EK, 3); break; } } LAUNCH_P8K_(AR, BR, EK, 4); } while (0)
