@@ -872,7 +872,6 @@ extern "C" int dvlp_p8_stamp_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMB
 #define P8_PH(v) do { } while (0)
 #define P8_PH_ACC(q) do { } while (0)
 #endif
-struct P8Stamps { unsigned long long t[5]; };
 
 // One 256 x 256 output tile at (m0, n0) over K tiles [kbeg, kbeg + 64 nk); `slab_out` non-null: raw fp32 partial (split-K).
 // EK = epilogue kind of whole tiles: 0 bias only, 1 bias + residual, 2 GELU forward (pre-activation out), 3 GELU backward
