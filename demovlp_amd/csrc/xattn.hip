@@ -339,7 +339,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
             for (int k = 0; k < NKG; ++k) pp[k] = 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(g < a.G ? pp[k] : 0.f); }
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.Gp && a.stop != 7) P1[(int64_t)w * a.Gp + g] = from_f<T>(g < a.G ? pp[k] : 0.f); }
     }
     if (a.stop == 2) return;
     // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
 #pragma unroll
         for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = w < a.W ? a.lam * (sv[k] * ci[k] + mc[k]) : 0.f; }
         focal_softmax<NKW, false, sizeof(T) == 2, PAIR>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
-        if (ok) {
+        if (ok && a.stop != 7) {                     // (stop 7: timing ablation -- no P1 / P2 stores)
             if constexpr (PAIR) {
 #pragma unroll
                 for (int k = 0; k < NKW; k += 2) {              // Wp is a multiple of 8: a pair is inside the row or outside it

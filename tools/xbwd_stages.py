@@ -39,7 +39,7 @@ ops.call("dvlp_xattn_bwd_stop", 0)
 ops.call("dvlp_xattn_bwd_variant", 1)
 
 # forward kernel (same stops): time of dvlp_xattn_fwd with the softmax kernel cut after each stage
-for stop in (0, 6, 5, 1, 2):
+for stop in (0, 6, 5, 1, 2, 7):          # 7: everything but the P1 / P2 stores of the softmax kernel
     ops.call("dvlp_xattn_bwd_stop", stop)
     ts = []
     for rep in range(5):
