@@ -1320,14 +1320,18 @@ extern "C" int dvlp_attention_bwd_colsum_next(float* dst) { t_attn_csum_next = d
 extern "C" int dvlp_attention_bwd_colsum_fused() { return t_attn_csum_fused; }
 static int g_attn_fold = 1;        // space-mode bf16: 1 = CLS query folded into the frame waves when the caller passes workspaces, 0 = separate launches (A/B, tests)
 extern "C" int dvlp_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
+static thread_local int t_attn_fwd_folded = 0;
+// 1 if the last dvlp_attention_fwd of this host thread folded the CLS query and filled `cls_stats` (only then may they be handed to the backward)
+extern "C" int dvlp_attention_fwd_folded() { return t_attn_fwd_folded; }
 
 // `workspace` (B*H*F*66 floats) + `cls_stats` (B*H*4 floats), both optional: space mode, bf16 -- the CLS query is folded into the
-// frame waves and its global softmax statistics are kept in `cls_stats` for dvlp_attention_bwd.  `cls_stats[0]` is set to NaN when
-// the fold did not apply (the backward then runs its own statistics pass).
+// frame waves and its global softmax statistics are kept in `cls_stats` for dvlp_attention_bwd.  dvlp_attention_fwd_folded() says
+// whether that happened (shape outside the fold's range, fp32, or the fold switched off: `cls_stats` is left untouched).
 extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
                                   const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
                                   float* cls_stats, void* stream) {
     dvlp_clear_status();
+    t_attn_fwd_folded = 0;
     AttnArgs a{};
     a.abl = g_attn_abl;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.out = out; a.ldo = ldo;
@@ -1362,7 +1366,7 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
             else if (nqt == 1 && nkt == 1) MFWD(1, 1, B * H * F, 1);
             else if (nqt == 1 && nkt == 2) MFWD(1, 2, B * H * F, 1);
             else if (nqt == 2 && nkt == 3) MFWD(2, 3, B * H * F, 1);
-            if (done && a.cls_o) hipLaunchKernelGGL(attn_fwd_cls_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(64), 0, st, a);
+            if (done && a.cls_o) { hipLaunchKernelGGL(attn_fwd_cls_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(64), 0, st, a); t_attn_fwd_folded = 1; }
             else if (done) {   // CLS query on the streaming VALU workgroup
                 AttnArgs c = a; c.seg_begin = nseg;
                 hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(1, (unsigned)H, (unsigned)B), block, lds, st, c);

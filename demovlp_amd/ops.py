@@ -287,6 +287,8 @@ def space_attention_fwd(qkv, addmask, B, F, R, want_stats=False):
         ws = _workspace("attn_fwd", B * HEADS * F * 66, qkv.device)
     call("dvlp_attention_fwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(base), ctypes.c_void_p(base + 768 * es),
          ctypes.c_void_p(base + 1536 * es), 2304, p(addmask), p(out), 768, SCALE, p(ws), p(stats), stream())
+    if stats is not None and not _lib.load().dvlp_attention_fwd_folded():
+        stats = None                                  # the fold was switched off (dvlp_attention_cls_fold): nothing was written
     return (out, stats) if want_stats else out
 
 

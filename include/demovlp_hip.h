@@ -131,6 +131,8 @@ int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int
                        void* stream);
 /* 1 (default): fold the CLS query where workspaces are given; 0: separate CLS launches -- for A/B measurements and tests */
 int dvlp_attention_cls_fold(int on);
+/* 1 if the last dvlp_attention_fwd of this host thread folded the CLS query and filled `cls_stats` (only then hand them to the backward) */
+int dvlp_attention_fwd_folded(void);
 /* the NEXT dvlp_attention_bwd (mode 0) issued by this host thread also queues the column sums of dq | dk | dv (fp32 [3*H*64]: the gradient
    of the packed qkv bias, object_transformer.py:310 qkv_bias=True) into `dst` through the deferred-reduction queue when it can (bf16 one-pass
    form with the forward's statistics); dvlp_attention_bwd_colsum_fused() = 1 if the last call did, else the caller sums the columns itself */

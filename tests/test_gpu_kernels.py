@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from demovlp_amd import ops, synthetic as syn  # noqa: E402
+from demovlp_amd import _lib, ops, synthetic as syn  # noqa: E402
 from oracle import restatement as orc  # noqa: E402
 
 DEV = "cuda"
@@ -171,6 +171,27 @@ def test_space_attention(dtype, B, F, R, attn_bwd_variant):
     cls_rows = torch.arange(B, device=DEV) * N
     assert rel(out[cls_rows], ref.reshape(B * N, 768)[cls_rows]) < tol(dtype)
     assert rel(dqkv[cls_rows], q.grad.reshape(B * N, 2304)[cls_rows]) < tol(dtype) * 2
+
+
+def test_space_attention_fold_switched_off():
+    """dvlp_attention_cls_fold(0): the forward leaves `cls_stats` untouched, says so through dvlp_attention_fwd_folded(), and the host
+    hands no statistics to the backward (which then runs its own pass) -- never uninitialised ones."""
+    B, F, R = 2, 8, 36
+    N = 1 + F * R
+    qkv = rnd(B * N, 2304, dtype=torch.bfloat16, scale=1.5)
+    addmask = torch.zeros(B, N, device=DEV)
+    dout = rnd(B * N, 768, dtype=torch.bfloat16, seed=2)
+    out1, st1 = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True)
+    assert st1 is not None and _lib.load().dvlp_attention_fwd_folded() == 1
+    d1 = ops.space_attention_bwd(qkv, addmask, dout, B, F, R, out=out1, stats=st1)
+    ops.call("dvlp_attention_cls_fold", 0)
+    try:
+        out0, st0 = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True)
+        assert st0 is None and _lib.load().dvlp_attention_fwd_folded() == 0
+        d0 = ops.space_attention_bwd(qkv, addmask, dout, B, F, R, out=out0, stats=st0)
+    finally:
+        ops.call("dvlp_attention_cls_fold", 1)
+    assert rel(out0, out1) < 1e-2 and rel(d0, d1) < 2e-2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
