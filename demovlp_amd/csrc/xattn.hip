@@ -309,6 +309,36 @@ __device__ __forceinline__ void focal_softmax(float (&e)[NK], float (&pp)[NK], i
     s_out = s;
 }
 
+// The bf16 kernels' form of the above (round 3: the sweeps are VALU-bound, ~27 issue slots per tile element before this, ~18 after).
+// The caller hands in the BASE-2 exponent argument, one fma per element: x[k] = S * (r lambda log2 e) + (lambda mask - |lambda|) log2 e,
+// -inf in the slots past the row's end (so no selects here).  With e = 2^x and sum = sum_k e:
+//   * focal_equal's test P n - sum(P) > 0 (loss.py:274-283) with P = e / sum is  e > sum / n : no normalised copy, no second reduction
+//     (the sum of the normalised entries is 1 up to rounding -- the test moves only for entries within an ulp of the threshold);
+//   * P' = gated e / sum(gated e): the 1 / sum factor cancels;
+//   * NEEDP (the backward needs P itself): e <- e / sum, s_out = sum(gated P).
+constexpr float XLOG2E = 1.4426950408889634f, XLN2 = 0.6931471805599453f;
+template <int NK, bool FULL, bool NEEDP>
+__device__ __forceinline__ void focal_softmax_fast(float (&e)[NK], float (&pp)[NK], float inv_n, int gate, float& s_out) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { e[k] = __builtin_amdgcn_exp2f(e[k]); sum += e[k]; }
+    sum = FULL ? wave_sum(sum) : half_sum(sum);
+    const float thr = gate ? sum * inv_n : -1.f;            // no gate: every entry passes (empty slots hold 0 either way)
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { pp[k] = e[k] > thr ? e[k] : 0.f; s += pp[k]; }
+    s = FULL ? wave_sum(s) : half_sum(s);
+    const float is = __builtin_amdgcn_rcpf(s);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) pp[k] *= is;
+    if constexpr (NEEDP) {
+        const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) e[k] *= inv;
+        s_out = s * inv;
+    }
+}
+
 // NKG = ceil(Gp / 64) entries per lane in the image->text sweep (one word per wave);
 // NKW = ceil(Wp / 32) entries per lane in the text->image sweep (one region per 32-lane half, two regions per wave)
 template <typename T, int NKG, int NKW>
@@ -325,36 +355,69 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
     const float* mimg = a.mimg + (int64_t)i * a.G;
     const float* mcap = a.mcap + (int64_t)j * a.W;
     // image -> text: for each word, softmax over regions (the caption-mask term is constant along this axis)
+    constexpr bool FAST = sizeof(T) == 2;            // bf16: focal_softmax_fast (base-2 exponent arguments, see there)
+    const float l2 = a.lam * XLOG2E, sh = fabsf(a.lam) * XLOG2E;
     float mi[NKG], ri[NKG];
+    int go[NKG];                                     // row offsets, clamped: the tile reads below are unconditional (no branch, one wait for all)
 #pragma unroll
-    for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; mi[k] = g < a.G ? mimg[g] : 0.f; ri[k] = g < a.G ? rn[g] : 0.f; }
+    for (int k = 0; k < NKG; ++k) {
+        const int g = lane + 64 * k;
+        go[k] = (g < a.G ? g : a.G - 1) * a.Wq;
+        if constexpr (FAST) { mi[k] = g < a.G ? mimg[g] * l2 - sh : -INFINITY; ri[k] = g < a.G ? rn[g] * l2 : 0.f; }
+        else { mi[k] = g < a.G ? mimg[g] : 0.f; ri[k] = g < a.G ? rn[g] : 0.f; }
+    }
+    const float inv_G = 1.f / (float)a.G;
     for (int w = wid; w < a.Wp; w += nw) {
         float e[NKG], pp[NKG], s;
         if (w < a.W) {
+            if constexpr (FAST) {
 #pragma unroll
-            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; e[k] = g < a.G ? a.lam * (Ssm[g * a.Wq + w] * ri[k] + mi[k]) : 0.f; }
-            focal_softmax<NKG, true, sizeof(T) == 2>(e, pp, a.G, lane, a.gate, fabsf(a.lam), s);
+                for (int k = 0; k < NKG; ++k) e[k] = fmaf(Ssm[go[k] + w], ri[k], mi[k]);
+                focal_softmax_fast<NKG, true, false>(e, pp, inv_G, a.gate, s);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; const float sv = Ssm[go[k] + w]; e[k] = g < a.G ? a.lam * (sv * ri[k] + mi[k]) : 0.f; }
+                focal_softmax<NKG, true, false>(e, pp, a.G, lane, a.gate, fabsf(a.lam), s);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < NKG; ++k) pp[k] = 0.f;
         }
+        if (a.stop != 7) {                           // (stop 7: timing ablation -- no P1 / P2 stores)
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.Gp && a.stop != 7) P1[(int64_t)w * a.Gp + g] = from_f<T>(g < a.G ? pp[k] : 0.f); }
+            for (int k = 0; k < NKG; ++k) {          // NKG = ceil(Gp / 64): only the last block can be ragged; empty slots hold 0
+                const int g = lane + 64 * k;
+                if (k < NKG - 1 || g < a.Gp) P1[(int64_t)w * a.Gp + g] = from_f<T>(pp[k]);
+            }
+        }
     }
     if (a.stop == 2) return;
     // text -> image: for each region, softmax over words (the region-mask term is constant along this axis)
     constexpr bool PAIR = NKW % 2 == 0;
     float mc[NKW], ci[NKW];
+    int wo[NKW];                                     // word offsets, clamped (unconditional tile reads)
 #pragma unroll
-    for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; }
+    for (int k = 0; k < NKW; ++k) {
+        const int w = wslot<PAIR>(hl, k);
+        wo[k] = w < a.W ? w : 0;
+        if constexpr (FAST) { mc[k] = w < a.W ? mcap[w] * l2 - sh : -INFINITY; ci[k] = w < a.W ? cn[w] * l2 : 0.f; }
+        else { mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; }
+    }
+    const float inv_W = 1.f / (float)a.W;
     for (int g0 = 2 * wid; g0 < a.G; g0 += 2 * nw) {
         const int g = g0 + half;
         const bool ok = g < a.G;
         const int gc = ok ? g : a.G - 1;
         float e[NKW], pp[NKW], sv[NKW], s;
+        if constexpr (FAST) {
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); sv[k] = w < a.W ? Ssm[gc * a.Wq + w] : 0.f; e[k] = w < a.W ? a.lam * (sv[k] * ci[k] + mc[k]) : 0.f; }
-        focal_softmax<NKW, false, sizeof(T) == 2, PAIR>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
+            for (int k = 0; k < NKW; ++k) { sv[k] = Ssm[gc * a.Wq + wo[k]]; e[k] = fmaf(sv[k], ci[k], mc[k]); }   // (sv of an empty slot only ever meets pp = 0)
+            focal_softmax_fast<NKW, false, false>(e, pp, inv_W, a.gate, s);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); const float x = Ssm[gc * a.Wq + wo[k]]; sv[k] = w < a.W ? x : 0.f; e[k] = w < a.W ? a.lam * (sv[k] * ci[k] + mc[k]) : 0.f; }
+            focal_softmax<NKW, false, false, PAIR>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
+        }
         if (ok && a.stop != 7) {                     // (stop 7: timing ablation -- no P1 / P2 stores)
             if constexpr (PAIR) {
 #pragma unroll
@@ -374,7 +437,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_fwd_kernel(PairArgs a) {
         if (a.u2) {                                 // Gram form: u_g = sum_w P2[g,w] S_raw[g,w] with the probabilities as stored
             float uu = 0.f;
 #pragma unroll
-            for (int k = 0; k < NKW; ++k) uu += to_f(from_f<T>(pp[k])) * (sv[k] > 0.f ? sv[k] : 10.f * sv[k]);
+            for (int k = 0; k < NKW; ++k) uu += to_f(from_f<T>(pp[k])) * fminf(sv[k], 10.f * sv[k]);      // LeakyReLU_0.1 undone: min(s, 10 s)
             uu = half_sum(uu);
             if (ok && hl == 0) a.u2[((int64_t)j * a.Bi + i) * a.G + g] = uu;
         }
@@ -549,18 +612,25 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
     const float* mcap = a.mcap + (int64_t)j * a.W;
     float d2v[IT2][NKW];                        // dA2 c of the rows this half owns, for the last pass
     uint32_t* Su = (uint32_t*)Ssm;
+    const float l2 = a.lam * XLOG2E, sh = fabsf(a.lam) * XLOG2E;        // focal_softmax_fast's exponent scaling
     {
-        float mi[NKG], ri[NKG], rd[NKG];
+        float mi[NKG], ri2[NKG], rd[NKG];       // ri2 = r lambda log2 e: lambda r = ri2 ln 2 (the lambda of dA is folded into it / applied at the end)
+        int go[NKG];                            // clamped row offsets: unconditional tile reads (an empty slot's value only ever meets P = 0)
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; mi[k] = g < a.G ? mimg[g] : 0.f; ri[k] = g < a.G ? rn[g] : 0.f; rd[k] = 0.f; }
+        for (int k = 0; k < NKG; ++k) {
+            const int g = lane + 64 * k;
+            go[k] = (g < a.G ? g : a.G - 1) * a.Wq;
+            mi[k] = g < a.G ? mimg[g] * l2 - sh : -INFINITY; ri2[k] = g < a.G ? rn[g] * l2 : 0.f; rd[k] = 0.f;
+        }
+        const float inv_G = 1.f / (float)a.G;
 #pragma unroll
         for (int it = 0; it < IT1; ++it) {
             const int w = wid + NW * it;
             if (w >= a.W) break;
             float e[NKG], pp[NKG], sv[NKG], s;
 #pragma unroll
-            for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; sv[k] = g < a.G ? Ssm[g * a.Wq + w] : 0.f; e[k] = a.lam * (sv[k] * ri[k] + mi[k]); }
-            focal_softmax<NKG, true, true>(e, pp, a.G, lane, a.gate, fabsf(a.lam), s);
+            for (int k = 0; k < NKG; ++k) { sv[k] = Ssm[go[k] + w]; e[k] = fmaf(sv[k], ri2[k], mi[k]); }
+            focal_softmax_fast<NKG, true, true>(e, pp, inv_G, a.gate, s);
             float dpp[NKG], d1 = 0.f;
 #pragma unroll
             for (int k = 0; k < NKG; ++k) { dpp[k] = unpack(d1p[it], k); d1 += dpp[k] * pp[k]; }
@@ -573,13 +643,13 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
 #pragma unroll
             for (int k = 0; k < NKG; ++k) {
                 const int g = lane + 64 * k;
-                const float dA = a.lam * e[k] * (dpp[k] - d2);           // softmax backward, times lambda
-                if (g < a.G) Su[g * a.Wq + w] = __float_as_uint(sv[k]) | (uint32_t)__builtin_bit_cast(unsigned short, (bf16)(dA * ri[k]));
-                rd[k] += dA * sv[k];
+                const float t = e[k] * (dpp[k] - d2);                    // softmax backward; dA = lambda t
+                if (g < a.G) Su[go[k] + w] = __float_as_uint(sv[k]) | (uint32_t)__builtin_bit_cast(unsigned short, (bf16)(t * (ri2[k] * XLN2)));
+                rd[k] += t * sv[k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.G) rpart[wid * a.G + g] = rd[k]; }
+        for (int k = 0; k < NKG; ++k) { const int g = lane + 64 * k; if (g < a.G) rpart[wid * a.G + g] = a.lam * rd[k]; }
     }
     if (a.stop == 2) return;
     constexpr bool PAIR = NKW % 2 == 0;         // word slots as adjacent pairs (wslot): rows of dP2 / T / dS move as 4-byte pieces
@@ -602,9 +672,15 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
     }
     {
         constexpr int W32 = 32 * NKW;
-        float mc[NKW], ci[NKW], cd[NKW];
+        float mc[NKW], ci2[NKW], cd[NKW];
+        int wo[NKW];
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) { const int w = wslot<PAIR>(hl, k); mc[k] = w < a.W ? mcap[w] : 0.f; ci[k] = w < a.W ? cn[w] : 0.f; cd[k] = 0.f; }
+        for (int k = 0; k < NKW; ++k) {
+            const int w = wslot<PAIR>(hl, k);
+            wo[k] = w < a.W ? w : 0;
+            mc[k] = w < a.W ? mcap[w] * l2 - sh : -INFINITY; ci2[k] = w < a.W ? cn[w] * l2 : 0.f; cd[k] = 0.f;
+        }
+        const float inv_W = 1.f / (float)a.W;
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
             const int g = 2 * wid + half + 2 * NW * it;
@@ -614,18 +690,17 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
             float e[NKW], pp[NKW], sv[NKW], s;
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
-                const int w = wslot<PAIR>(hl, k);
-                sv[k] = w < a.W ? __uint_as_float(Su[gc * a.Wq + w] & 0xffff0000u) : 0.f;
-                e[k] = a.lam * (sv[k] * ci[k] + mc[k]);
+                sv[k] = __uint_as_float(Su[gc * a.Wq + wo[k]] & 0xffff0000u);
+                e[k] = fmaf(sv[k], ci2[k], mc[k]);
             }
-            focal_softmax<NKW, false, true, PAIR>(e, pp, a.W, hl, a.gate, fabsf(a.lam), s);
+            focal_softmax_fast<NKW, false, true>(e, pp, inv_W, a.gate, s);
             float dpp[NKW], d1 = 0.f;
             float alpha = 0.f, beta = 0.f;
             if (gram) { alpha = ab[2 * gc]; beta = ab[2 * gc + 1]; }
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
                 dpp[k] = unpack(d2p[it], k);
-                if (gram) dpp[k] = alpha * (sv[k] > 0.f ? sv[k] : 10.f * sv[k]) - beta * dpp[k];      // dP2 = alpha S_raw - beta (P2 Kq)
+                if (gram) dpp[k] = alpha * fminf(sv[k], 10.f * sv[k]) - beta * dpp[k];      // dP2 = alpha S_raw - beta (P2 Kq); S_raw = min(s, 10 s) undoes LeakyReLU_0.1
                 d1 += dpp[k] * pp[k];
             }
             d1 = half_sum(d1);
@@ -636,9 +711,9 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
             d2 = half_sum(d2);
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
-                const float dA = ok ? a.lam * e[k] * (dpp[k] - d2) : 0.f;
-                d2v[it][k] = dA * ci[k];
-                cd[k] += dA * sv[k];
+                const float t = ok ? e[k] * (dpp[k] - d2) : 0.f;         // dA = lambda t; lambda c = ci2 ln 2
+                d2v[it][k] = t * (ci2[k] * XLN2);
+                cd[k] += t * sv[k];
                 if (gram) {
                     // u depends on S_raw directly: dS_raw += alpha P2 (scaled so that the LeakyReLU' factor of the last pass leaves it as it
                     // is), and beta P2 replaces T for the dKq product
@@ -664,7 +739,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + wslot<PAIR>(hl, k)] = cd[k];
+        for (int k = 0; k < NKW; ++k) qpart[(2 * wid + half) * W32 + wslot<PAIR>(hl, k)] = a.lam * cd[k];
     }
     if (a.stop == 3) { if (d2v[0][0] == 123.456f) rn[0] = 1.f; return; }
     __syncthreads();
