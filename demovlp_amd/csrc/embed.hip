@@ -58,30 +58,69 @@ __global__ void embed_unassemble_kernel(int B, int F, int R, const T* __restrict
     for (int d = threadIdx.x; d < EMB; d += blockDim.x) dtok[m * EMB + d] = dx[src * EMB + d];
 }
 
-// stage 1 of dWp[d][c] = sum_m dtok[m][d] * box[m][c]: partial[p][c][d]
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) { const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void ld4(const bf16* p, float (&o)[4]) { const bf16x4 v = *(const bf16x4*)p; o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+// stage 1 of dWp[d][c] = sum_m dtok[m][d] * box[m][c]: partial[p][c][d].  One workgroup per chunk of rows, 192 threads x 4 columns (8- /
+// 16-byte row pieces), eight rows in flight per thread; the six box values of a row are workgroup-uniform (scalar loads).
 template <typename T>
-__global__ void box_wgrad_kernel(int64_t M, const T* __restrict__ dtok, const float* __restrict__ box, int64_t rows_per, float* __restrict__ partial) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= EMB) return;
-    const int64_t m0 = (int64_t)blockIdx.y * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
-    float acc[BOX];
+__global__ __launch_bounds__(192) void box_wgrad_kernel(int64_t M, const T* __restrict__ dtok, const float* __restrict__ box, int64_t rows_per, float* __restrict__ partial) {
+    const int d = threadIdx.x * 4;
+    const int64_t m0 = (int64_t)blockIdx.x * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
+    float acc[BOX][4];
 #pragma unroll
-    for (int c = 0; c < BOX; ++c) acc[c] = 0.f;
-    for (int64_t m = m0; m < m1; ++m) {
-        const float g = to_f(dtok[m * EMB + d]);
+    for (int c = 0; c < BOX; ++c)
 #pragma unroll
-        for (int c = 0; c < BOX; ++c) acc[c] += g * box[m * BOX + c];
+        for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+    constexpr int UR = 8;
+    int64_t m = m0;
+    for (; m + UR <= m1; m += UR) {
+        float g[UR][4];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) ld4(dtok + (m + u) * EMB + d, g[u]);
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+#pragma unroll
+            for (int c = 0; c < BOX; ++c) {
+                const float b = box[(m + u) * BOX + c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[c][j] += g[u][j] * b;
+            }
+    }
+    for (; m < m1; ++m) {
+        float g[4];
+        ld4(dtok + m * EMB + d, g);
+#pragma unroll
+        for (int c = 0; c < BOX; ++c) {
+            const float b = box[m * BOX + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] += g[j] * b;
+        }
     }
 #pragma unroll
-    for (int c = 0; c < BOX; ++c) partial[((int64_t)blockIdx.y * BOX + c) * EMB + d] = acc[c];
+    for (int c = 0; c < BOX; ++c) *(float4*)(partial + ((int64_t)blockIdx.x * BOX + c) * EMB + d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
 }
-__global__ void box_wgrad_reduce_kernel(int64_t P, const float* __restrict__ partial, float* __restrict__ dWp, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // i = c*EMB + d
-    if (i >= BOX * EMB) return;
-    const int c = i / EMB, d = i % EMB;
+// stage 2: 64 outputs x 16 slices of the P partial planes per workgroup, every load of a thread in flight at once (the one-thread-per-output
+// loop over 256 planes was a chain of dependent loads: 95 us)
+__global__ __launch_bounds__(1024) void box_wgrad_reduce_kernel(int64_t P, const float* __restrict__ partial, float* __restrict__ dWp, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;    // i = c*EMB + d  (BOX * EMB is a multiple of 64)
+    float s16[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int64_t pp = q + 16 * u; s16[u] = pp < P ? partial[pp * BOX * EMB + i] : 0.f; }
     float s = 0.f;
-    for (int64_t p = 0; p < P; ++p) s += partial[p * BOX * EMB + i];
-    dWp[d * BOX + c] = accumulate ? dWp[d * BOX + c] + s : s;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += s16[u];
+    for (int64_t pp = q + 256; pp < P; pp += 16) s += partial[pp * BOX * EMB + i];
+    red[q][lane] = s;
+    __syncthreads();
+    if (q == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        const int c = i / EMB, d = i % EMB;
+        dWp[d * BOX + c] = accumulate ? dWp[d * BOX + c] + t : t;
+    }
 }
 
 // DistilBERT embeddings: e = word[id] + pos[l] (saved), y = LN(e)
@@ -183,11 +222,12 @@ extern "C" int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const floa
     if (M <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = dvlp_box_wgrad_chunks(M), rows_per = cdiv(M, P);
-    dim3 grid(3, (unsigned)P), block(256);
+    dim3 grid((unsigned)P), block(192);
     if (dtype == DVLP_F32) hipLaunchKernelGGL(box_wgrad_kernel<float>, grid, block, 0, st, M, (const float*)dtok, box, rows_per, workspace);
     else if (dtype == DVLP_BF16) hipLaunchKernelGGL(box_wgrad_kernel<bf16>, grid, block, 0, st, M, (const bf16*)dtok, box, rows_per, workspace);
     else return DVLP_ERR_DTYPE;
-    hipLaunchKernelGGL(box_wgrad_reduce_kernel, dim3((BOX * EMB + 255) / 256), dim3(256), 0, st, P, workspace, dWp, accumulate);
+    static_assert(BOX * EMB % 64 == 0 && EMB == 192 * 4, "box_wgrad kernels' thread maps");
+    hipLaunchKernelGGL(box_wgrad_reduce_kernel, dim3(BOX * EMB / 64), dim3(1024), 0, st, P, workspace, dWp, accumulate);
     return dvlp_launch_status();
 }
 
