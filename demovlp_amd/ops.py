@@ -194,10 +194,12 @@ def _ensure_colsum_counters(device):
 _DEFER = {}
 
 
-def enable_deferred_reductions(device, workspace_mb=384, max_items=4096):
+def enable_deferred_reductions(device, workspace_mb=1024, max_items=4096):
     """Let gradient column sums that are written straight into a gradient arena (``defer=True`` below) postpone their final
     reduction to ONE batched launch at :func:`flush_reductions`.  The trainer enables this and flushes before the
-    optimizer step; without it every such call reduces immediately."""
+    optimizer step; without it every such call reduces immediately.  (A B = 64 step queues ~390 MB of partial rows -- 37 LayerNorm
+    backward launches of 1024 workgroups x 2-3 planes x 768 floats are most of it; a call that finds the workspace full reduces on the
+    spot, which costs a launch of its own.)"""
     key = str(device)
     if key not in _DEFER:
         ws = torch.empty(int(workspace_mb) << 18, device=device, dtype=torch.float32)
