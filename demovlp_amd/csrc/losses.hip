@@ -24,6 +24,7 @@ struct LossArgs {
     float temperature, lam;
     int use_global, use_local, stages;   // stages: 1 = sim forward, 2 = losses + dsim/dxs, 4 = embedding grads from dsim
     int staged;              // both embedding matrices fit in LDS (B <= 64): rows are read from there
+    int mf;                  // bf16, B in {32, 64}: the B x B x 256 products run on the matrix cores (see loss_kernel)
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -63,7 +64,32 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
         }
         __syncthreads();
     }
-    if (a.use_global && (a.stages & 1)) {
+    // Matrix-core form of the three products (bf16 embeddings, B a multiple of 32).  As one-wave-per-entry dot products they read
+    // two 1-KB rows from LDS per entry -- 8 MB per product through one CU's LDS port, ~60 of this launch's 82 us at B = 64.
+    // sim = gt go^T: both operands are plain 16-byte row reads (k = channel).  The two gradient products contract over ROWS (k = o or t):
+    // the A operand is dsim (or its transpose) times the other side's reciprocal norm, split into a bf16 head and a bf16 remainder (two
+    // MFMAs: ~2^-17 relative, fp32 for this purpose), the B operand gathers eight rows' values of one channel.
+    if constexpr (sizeof(T) == 2) {
+        if (a.use_global && (a.stages & 1) && a.mf) {
+            const int nT = B >> 4;
+            for (int tile = wid; tile < nT * nT; tile += nw) {
+                const int ti = tile / nT, oi = tile % nT;
+                const bf16* ar = (const bf16*)gt + (int64_t)(ti * 16 + (lane & 15)) * LD_ + (lane >> 4) * 8;
+                const bf16* br = (const bf16*)go + (int64_t)(oi * 16 + (lane & 15)) * LD_ + (lane >> 4) * 8;
+                bf16x8 af[8], bq[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) { af[kk] = *(const bf16x8*)(ar + kk * 32); bq[kk] = *(const bf16x8*)(br + kk * 32); }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bq[kk], acc, 0, 0, 0);
+                const int o = oi * 16 + (lane & 15);                 // lane holds D[text row 4 (lane >> 4) + r][object row lane & 15]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int t = ti * 16 + 4 * (lane >> 4) + r; a.sim[t * B + o] = acc[r] * (rnt[t] * rno[o]); }
+            }
+            __syncthreads();
+        }
+    }
+    if (a.use_global && (a.stages & 1) && !a.mf) {
         // sim[t][o]: one wave per entry
         for (int e = wid; e < B * B; e += nw) {
             const int t = e / B, o = e % B;
@@ -104,14 +130,63 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
     if (a.use_global && (a.stages & 4)) {
         // d/d normalised rows, then through a / max(|a|, eps)
         float* Ds = E + 2 * B * LD_;                 // staged: dsim [B][B] (the row loop below re-read it from global memory entry by entry)
-        if (a.staged) {
+        if (a.staged || a.mf) {
             for (int e = threadIdx.x; e < B * B; e += blockDim.x) Ds[e] = a.dsim[e];
             __syncthreads();
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (a.mf) {
+                // wave = one 16-channel tile of both gradient matrices; the un-normalised sums land in E ([2B][256], free in this mode)
+                const int nK = B >> 5, g8 = (lane >> 4) * 8;
+                for (int ci = wid; ci < LD_ / 16; ci += nw) {
+                    const int c = ci * 16 + (lane & 15);
+                    bf16x8 gof[2], gtf[2];
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (kk >= nK) break;
+                            gof[kk][i] = ((const bf16*)go)[(int64_t)(kk * 32 + g8 + i) * LD_ + c];
+                            gtf[kk][i] = ((const bf16*)gt)[(int64_t)(kk * 32 + g8 + i) * LD_ + c];
+                        }
+                    for (int rt = 0; rt < (B >> 4); ++rt) {
+                        const int rr = rt * 16 + (lane & 15);
+                        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            if (kk >= nK) break;
+                            const int k0 = kk * 32 + g8;
+                            bf16x8 h1, l1, h2, l2;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const float w1 = Ds[rr * B + k0 + i] * rno[k0 + i];       // d/d text row rr: over object rows
+                                const float w2 = Ds[(k0 + i) * B + rr] * rnt[k0 + i];     // d/d object row rr: over text rows
+                                h1[i] = (bf16)w1; l1[i] = (bf16)(w1 - (float)h1[i]);
+                                h2[i] = (bf16)w2; l2[i] = (bf16)(w2 - (float)h2[i]);
+                            }
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, gof[kk], acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, gof[kk], acc1, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h2, gtf[kk], acc2, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l2, gtf[kk], acc2, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = rt * 16 + 4 * (lane >> 4) + r;
+                            E[i * LD_ + c] = acc1[r]; E[(B + i) * LD_ + c] = acc2[r];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
         }
         for (int r = wid; r < 2 * B; r += nw) {
             const bool row = r < B; const int idx = row ? r : r - B;
             const float* ron = row ? rno : rnt;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.mf) {
+                const float4 t4 = *(const float4*)&E[r * LD_ + lane * 4];
+                acc[0] = t4.x; acc[1] = t4.y; acc[2] = t4.z; acc[3] = t4.w;
+            } else
             for (int k = 0; k < B; ++k) {
                 const float w = (a.staged ? (row ? Ds[idx * B + k] : Ds[k * B + idx]) : (row ? a.dsim[idx * B + k] : a.dsim[k * B + idx])) * ron[k];
                 float y[4];
@@ -161,6 +236,8 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
     if (threadIdx.x == 0 && (a.stages & 2)) { a.losses[0] = gl + ll; a.losses[1] = gl; a.losses[2] = ll; }
 }
 
+static int g_loss_mfma = 1;
+extern "C" int dvlp_loss_mfma(int on) { g_loss_mfma = on; return DVLP_OK; }
 // sim / dsim: fp32 [B*B] each.  stages (bitmask): 1 = sim_matrix forward (gt, go -> sim); 2 = losses from sim / xs, with
 // dsim = d global / d sim and dxs = d local / d xs; 4 = sim_matrix backward (dsim -> dgt, dgo).  7 = everything in one launch.
 extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,
@@ -169,9 +246,10 @@ extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const voi
     dvlp_clear_status();
     if (d != LD_ || B <= 0 || B > 2048) return DVLP_ERR_SHAPE;
     if (use_local && !xs) return DVLP_ERR_SHAPE;
-    const int staged = B <= 64 ? 1 : 0;
-    LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages, staged};
-    const size_t lds = (size_t)(6 * B + 32 + (staged ? 2 * B * LD_ + B * B : 0)) * sizeof(float);
+    const int mf = (dtype == DVLP_BF16 && (B == 32 || B == 64) && g_loss_mfma) ? 1 : 0;
+    const int staged = (B <= 64 && !mf) ? 1 : 0;
+    LossArgs a{gt, go, xs, sim, dsim, dgt, dgo, dxs, losses, (int)B, temperature, lam, use_global, use_local, stages, staged, mf};
+    const size_t lds = (size_t)(6 * B + 32 + ((staged || mf) ? 2 * B * LD_ + B * B : 0)) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     { static bool once = false; if (!once) { once = true;
         (void)hipFuncSetAttribute((const void*)loss_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -212,6 +212,9 @@ int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int6
 int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,
                            float lam, int use_global, int use_local, int stages, float* sim, float* dsim, void* dgt, void* dgo,
                            float* dxs, float* losses, void* stream);
+/* 1 (default): bf16 embeddings with B = 32 / 64 run the three B x B x 256 products of the launch on the matrix cores; 0: the
+ * one-wave-per-entry form used for every other shape -- for A/B measurements and tests */
+int dvlp_loss_mfma(int on);
 
 /* rectangular sim_matrix (model/model.py:582-590 on [N,256] x [M,256], e.g. the whole eval set at trainer/trainer_dist.py:369):
    xn (fp32) = x / max(|x|, 1e-8) row-wise and norm = |x|; the [N,M] product and its two gradient products are dvlp_gemm calls in

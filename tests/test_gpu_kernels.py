@@ -296,7 +296,7 @@ def _xattn_case(dtype, Bi, Bj, G, W, gate):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B", [2, 16, 64])
+@pytest.mark.parametrize("B", [2, 16, 32, 64])
 def test_loss_heads(dtype, B):
     a, b = rnd(B, 256, dtype=dtype), rnd(B, 256, dtype=dtype, seed=1)
     b = (b.float() + 0.5 * a.float()).to(dtype)
@@ -314,6 +314,26 @@ def test_loss_heads(dtype, B):
     assert float((r["dgt"].float() - ar.grad).abs().max()) < t * float(ar.grad.abs().max()) + 1e-7
     assert float((r["dgo"].float() - br.grad).abs().max()) < t * float(br.grad.abs().max()) + 1e-7
     assert float((r["dxs"] - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("B", [32, 64])
+def test_loss_heads_matrix_core_form(B):
+    """bf16, B = 32 / 64: sim_matrix and its two gradient products on the matrix cores (dsim split into two bf16 pieces) against the
+    one-wave-per-entry fp32 form of the same launch: the products agree to fp32 rounding, the bf16 gradients to one bf16 step."""
+    a, b = rnd(B, 256, dtype=torch.bfloat16), rnd(B, 256, dtype=torch.bfloat16, seed=1)
+    xs = (torch.rand(B, B, generator=torch.Generator().manual_seed(2)) * 0.3 + 0.4 + 0.2 * torch.eye(B)).to(DEV)
+    r1 = ops.global_local_loss(a, b, xs, 0.05, 20.0, 1, 1, 7)
+    r1 = {k: v.clone() for k, v in r1.items()}
+    ops.call("dvlp_loss_mfma", 0)
+    try:
+        r0 = ops.global_local_loss(a, b, xs, 0.05, 20.0, 1, 1, 7)
+    finally:
+        ops.call("dvlp_loss_mfma", 1)
+    assert float((r1["sim"] - r0["sim"]).abs().max()) < 2e-6
+    assert float((r1["losses"] - r0["losses"]).abs().max()) < 1e-5 * float(r0["losses"].abs().max())
+    for k in ("dgt", "dgo"):
+        assert float((r1[k].float() - r0[k].float()).abs().max()) <= 2.0 ** -7 * float(r0[k].float().abs().max())
+    assert torch.equal(r1["dxs"], r0["dxs"])
 
 
 @pytest.mark.parametrize("sample,R", [(0, 36), (1, 36), (2, 36), (3, 30), (2, 30), (1, 30)])
