@@ -153,9 +153,11 @@ class RegionBatcher:
         for f, idx in enumerate(frame_idxs):
             self.stage(b, f, *read_frame_npz(os.path.join(frame_dir, f"{idx}.npz")))
 
-    def to_device(self):
+    def to_device(self, out=None):
         """-> (object [B,F,R,2054] f32, object_mask [B,F,R] f32, object_len [B,F] int32), all on the device.  Returns as soon as
-        the copies and the selection kernel are enqueued; the next batch may be staged immediately (into the other buffer set)."""
+        the copies and the selection kernel are enqueued; the next batch may be staged immediately (into the other buffer set).
+        ``out``: a dict with 'object' / 'object_mask' tensors (``GraphedTrainStep.inputs``) the selection writes into -- from the
+        thread that runs the step only (see there)."""
         from . import ops
         if self.device.type != "cuda":
             raise ops._lib.DemoVLPHipError("RegionBatcher.to_device needs a ROCm device: there is no CPU fallback")
@@ -172,7 +174,8 @@ class RegionBatcher:
         for t in d:
             t.record_stream(cur)
         self.cur = (self.cur + 1) % len(self.bufs)
-        obj, mask, _order, lens = ops.region_select(d[0], d[1], d[2], d[3], self.R, nvalid=d[4])
+        obj, mask, _order, lens = ops.region_select(d[0], d[1], d[2], d[3], self.R, nvalid=d[4],
+                                                    out=None if out is None else (out["object"], out["object_mask"]))
         return obj, mask, lens
 
 

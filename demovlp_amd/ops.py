@@ -505,13 +505,19 @@ def rownorm_bwd(x, norm, dxn):
 # ----------------------------------------------------------------------------------------------------------------
 # region select, optimizer
 # ----------------------------------------------------------------------------------------------------------------
-def region_select(feats, bbox, conf, wh, R, nvalid=None):
+def region_select(feats, bbox, conf, wh, R, nvalid=None, out=None):
     """feats [B,F,Nraw,2048], bbox [B,F,Nraw,4], conf [B,F,Nraw], wh [B,F,2] (fp32, on device) ->
-    obj [B,F,R,2054] fp32, mask [B,F,R] fp32, order [B,F,R] int32, lens [B,F] int32."""
+    obj [B,F,R,2054] fp32, mask [B,F,R] fp32, order [B,F,R] int32, lens [B,F] int32.  ``out`` = (obj, mask): write there."""
     B, F, Nraw, _ = feats.shape
     dev = feats.device
-    obj = torch.empty((B, F, R, 2054), device=dev, dtype=torch.float32)
-    mask = torch.empty((B, F, R), device=dev, dtype=torch.float32)
+    if out is not None:
+        obj, mask = out
+        for t, shp in ((obj, (B, F, R, 2054)), (mask, (B, F, R))):
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise ValueError(f"region_select: out tensor must be contiguous fp32 {shp} on {dev}")
+    else:
+        obj = torch.empty((B, F, R, 2054), device=dev, dtype=torch.float32)
+        mask = torch.empty((B, F, R), device=dev, dtype=torch.float32)
     order = torch.empty((B, F, R), device=dev, dtype=torch.int32)
     lens = torch.empty((B, F), device=dev, dtype=torch.int32)
     call("dvlp_region_select", B * F, F, Nraw, R, p(feats), p(bbox), p(conf), p(wh), p(nvalid), p(obj), p(mask), p(order), p(lens),

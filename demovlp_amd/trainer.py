@@ -695,6 +695,20 @@ class GraphedTrainStep:
         self._run_pieces(data)
         return self.out
 
+    @property
+    def inputs(self):
+        """The captured graphs' input buffers ``{'text': {input_ids, attention_mask}, 'object', 'object_mask'}`` (None before the
+        capture).  A loader that writes a batch straight into them -- ``RegionBatcher.to_device(out=step.inputs)``, the selection
+        kernel's output IS the model's input -- and hands the same dict to ``__call__`` saves the device-to-device copy of the batch
+        (151 MB of region features at B = 64: ~65 us a step).  Write into them only from the thread / stream that replays the graphs:
+        stream order is what keeps batch n+1 from landing before step n has read batch n."""
+        return self.static if self.graphs is not None else None
+
+    @staticmethod
+    def _put(dst, src):
+        if src.data_ptr() != dst.data_ptr():                  # (already in place: the caller staged into `inputs`)
+            dst.copy_(src, non_blocking=True)
+
     def _capture(self, data):
         self.static = {"text": {k: v.clone() for k, v in data["text"].items()}, "object": data["object"].clone(),
                        "object_mask": data["object_mask"].clone()}
@@ -718,9 +732,9 @@ class GraphedTrainStep:
             self._capture(data)
         else:
             for k, v in data["text"].items():
-                self.static["text"][k].copy_(v, non_blocking=True)
-            self.static["object"].copy_(data["object"], non_blocking=True)
-            self.static["object_mask"].copy_(data["object_mask"], non_blocking=True)
+                self._put(self.static["text"][k], v)
+            self._put(self.static["object"], data["object"])
+            self._put(self.static["object_mask"], data["object_mask"])
         if not self.collective:
             # the captured AdamW kernels read lr / betas / eps / wd / the step counter from the device buffer: follow any change the
             # host made since the last call (param_groups[0]['lr'] = ..., load_state_dict) -- outside the graph, copies only on change

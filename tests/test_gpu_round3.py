@@ -618,3 +618,53 @@ def test_evaluate_with_two_ranks_matches_one_process():
         assert np.abs(res[rank][1] - one["o2t_sims"]).max() < 1e-5 * np.abs(one["o2t_sims"]).max()
         assert abs(res[rank][2] - one["val_loss"]) < 1e-5 * abs(one["val_loss"]) and res[rank][3] == one["nested_val_metrics"]["t2v_metrics"]["R5"]
     assert np.array_equal(res[0][1], res[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (h) the selection kernel writes a batch straight into the captured graphs' input buffers
+# ---------------------------------------------------------------------------------------------------------------------
+def test_region_batcher_stages_into_graph_inputs_and_the_step_matches_the_copying_path():
+    """``RegionBatcher.to_device(out=step.inputs)`` + ``step(step.inputs)``: the selection output is bit-identical to the
+    free-standing call and the replayed steps return exactly what they return when the batch is copied in."""
+    from demovlp_amd import functional as Fn
+    from demovlp_amd.data import RegionBatcher
+    F, R, B, NRAW = 8, 36, 2, 44
+    rb = RegionBatcher(B, F, R, max_regions=64, device=DEV)
+
+    def stage(seed):
+        for b in range(B):
+            for f in range(F):
+                fr = syn.make_frame(seed + b, f, NRAW)
+                rb.stage(b, f, fr["x"], fr["bbox"], fr["objects_conf"], (640.0, 360.0))
+
+    ids, att = syn.caption_batch(B, first_sample=0)
+    text = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(att).to(DEV)}
+    losses = []
+    for in_place in (False, True):
+        Fn.SHADOWS.clear()
+        model = build(F, R)
+        opt = FusedAdamW(ParamArena(model), lr=1e-4)
+        step = GraphedTrainStep(model, loss_head(), opt, warmup=2)
+        got = []
+        for it in range(6):                                     # 2 eager, the capture, 3 replays; a different clip set every step
+            stage(20 + 3 * it)
+            if in_place and step.inputs is not None:
+                ins = step.inputs
+                obj, mask, _ = rb.to_device(out=ins)
+                assert obj.data_ptr() == ins["object"].data_ptr() and mask.data_ptr() == ins["object_mask"].data_ptr()
+                for k, v in text.items():
+                    ins["text"][k].copy_(v)
+                data = ins
+            else:
+                obj, mask, _ = rb.to_device()
+                data = {"text": text, "object": obj, "object_mask": mask}
+            if it == 5:
+                stage(20 + 3 * it)
+                ref_obj, ref_mask, _ = rb.to_device()
+                assert torch.equal(ref_obj, data["object"]) and torch.equal(ref_mask, data["object_mask"])
+            got.append([float(t) for t in step(data)])
+        losses.append(got)
+    assert losses[0] == losses[1], (losses[0], losses[1])
+    with pytest.raises(ValueError):
+        ops.region_select(torch.zeros(1, 1, 4, 2048, device=DEV), torch.zeros(1, 1, 4, 4, device=DEV), torch.zeros(1, 1, 4, device=DEV),
+                          torch.ones(1, 1, 2, device=DEV), 4, out=(torch.zeros(1, 1, 4, 2054, device=DEV), torch.zeros(1, 1, 5, device=DEV)))
