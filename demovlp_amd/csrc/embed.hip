@@ -49,13 +49,40 @@ __global__ void embed_assemble_kernel(int B, int F, int R, const T* __restrict__
     if (threadIdx.x == 0) addmask[row] = (mask01[m] - 1.f) * 100.f;
 }
 
-// dtok[b*FR + t, :] = dx[b, 1+t, :]
+// dtok[b*FR + t, :] = dx[b, 1+t, :]   (16-byte pieces; a row is 768 elements)
 template <typename T>
-__global__ void embed_unassemble_kernel(int B, int F, int R, const T* __restrict__ dx, T* __restrict__ dtok) {
-    const int64_t m = blockIdx.x;
+__global__ __launch_bounds__(256) void embed_unassemble_kernel(int B, int F, int R, const T* __restrict__ dx, T* __restrict__ dtok) {
+    constexpr int PR = EMB * (int)sizeof(T) / 16;               // pieces per row
     const int FR = F * R;
-    const int64_t src = (m / FR) * (FR + 1) + 1 + (m % FR);
-    for (int d = threadIdx.x; d < EMB; d += blockDim.x) dtok[m * EMB + d] = dx[src * EMB + d];
+    const int64_t total = (int64_t)B * FR * PR;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / PR; const int pc = (int)(i % PR);
+        const int64_t src = (m / FR) * (FR + 1) + 1 + (m % FR);
+        ((uint4*)dtok)[m * PR + pc] = ((const uint4*)dx)[src * PR + pc];
+    }
+}
+
+// The heads' view of a tower output x [B][N][d]: row 0 of every sample (the CLS / global embedding) and rows 1.. (the local embeddings),
+// each contiguous (model/model.py:70-96 slices and calls .contiguous()) -- one launch; and its backward, dx assembled from the two
+// gradients in one launch (autograd's form of it is two zero fills, two strided copies and an add).  Raw 16-byte pieces: any dtype.
+__global__ __launch_bounds__(256) void split_cls_kernel(int64_t B, int64_t N, int PR, const uint4* __restrict__ x, uint4* __restrict__ g, uint4* __restrict__ l) {
+    const int64_t total = B * N * PR;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / PR; const int pc = (int)(i % PR);
+        const int64_t b = row / N, n = row % N;
+        const uint4 v = x[i];
+        if (n == 0) g[b * PR + pc] = v; else l[(b * (N - 1) + n - 1) * PR + pc] = v;
+    }
+}
+__global__ __launch_bounds__(256) void merge_cls_kernel(int64_t B, int64_t N, int PR, const uint4* __restrict__ dg, const uint4* __restrict__ dl, uint4* __restrict__ dx) {
+    const int64_t total = B * N * PR;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / PR; const int pc = (int)(i % PR);
+        const int64_t b = row / N, n = row % N;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n == 0) { if (dg) v = dg[b * PR + pc]; } else if (dl) v = dl[(b * (N - 1) + n - 1) * PR + pc];
+        dx[i] = v;
+    }
 }
 
 __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) { const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
@@ -208,10 +235,30 @@ extern "C" int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R,
     dvlp_clear_status();
     if (B <= 0 || F <= 0 || R <= 0) return DVLP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(B * F * R)), block(256);
+    const int64_t pieces = B * F * R * EMB / 4;                   // >= the 16-byte pieces of either dtype
+    dim3 grid((unsigned)(pieces / 256 < 4096 ? cdiv(pieces, 256) : 4096)), block(256);
     if (dtype == DVLP_F32) hipLaunchKernelGGL(embed_unassemble_kernel<float>, grid, block, 0, st, (int)B, (int)F, (int)R, (const float*)dx, (float*)dtok);
     else if (dtype == DVLP_BF16) hipLaunchKernelGGL(embed_unassemble_kernel<bf16>, grid, block, 0, st, (int)B, (int)F, (int)R, (const bf16*)dx, (bf16*)dtok);
     else return DVLP_ERR_DTYPE;
+    return dvlp_launch_status();
+}
+
+// x [B][N][row_bytes] -> g [B][row_bytes] (row 0), l [B][N-1][row_bytes] (rows 1..); row_bytes a multiple of 16, 16-byte aligned pointers
+extern "C" int dvlp_split_cls(int64_t B, int64_t N, int64_t row_bytes, const void* x, void* g, void* l, void* stream) {
+    dvlp_clear_status();
+    if (B <= 0 || N < 2 || row_bytes <= 0 || row_bytes % 16 || ((uintptr_t)x | (uintptr_t)g | (uintptr_t)l) % 16) return DVLP_ERR_SHAPE;
+    const int64_t pieces = B * N * (row_bytes / 16);
+    hipLaunchKernelGGL(split_cls_kernel, dim3((unsigned)(pieces / 256 < 4096 ? cdiv(pieces, 256) : 4096)), dim3(256), 0, (hipStream_t)stream, B, N,
+                       (int)(row_bytes / 16), (const uint4*)x, (uint4*)g, (uint4*)l);
+    return dvlp_launch_status();
+}
+// backward of the above: dx [B][N][row_bytes] from dg / dl (either may be NULL: zeros)
+extern "C" int dvlp_merge_cls(int64_t B, int64_t N, int64_t row_bytes, const void* dg, const void* dl, void* dx, void* stream) {
+    dvlp_clear_status();
+    if (B <= 0 || N < 2 || row_bytes <= 0 || row_bytes % 16 || ((uintptr_t)dx | (uintptr_t)dg | (uintptr_t)dl) % 16) return DVLP_ERR_SHAPE;
+    const int64_t pieces = B * N * (row_bytes / 16);
+    hipLaunchKernelGGL(merge_cls_kernel, dim3((unsigned)(pieces / 256 < 4096 ? cdiv(pieces, 256) : 4096)), dim3(256), 0, (hipStream_t)stream, B, N,
+                       (int)(row_bytes / 16), (const uint4*)dg, (const uint4*)dl, (uint4*)dx);
     return dvlp_launch_status();
 }
 

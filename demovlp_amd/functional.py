@@ -204,6 +204,27 @@ def _into(param, value):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# the heads' view of a tower output: (x[:, 0], x[:, 1:]), contiguous (model/model.py:70-96)
+# ----------------------------------------------------------------------------------------------------------------
+class SplitClsFn(torch.autograd.Function):
+    """x [B,N,d] -> (global [B,d], local [B,N-1,d]) in one launch; backward assembles dx from the two gradients in one launch
+    (autograd's own backward of ``x[:, 0].contiguous(), x[:, 1:].contiguous()``: two zero fills, two strided copies, an add)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.meta = (tuple(x.shape), x.dtype, x.device)
+        return ops.split_cls(x)
+
+    @staticmethod
+    def backward(ctx, dg, dl):
+        (B, N, d), dtype, device = ctx.meta
+        dg = None if dg is None else dg.to(dtype).contiguous()
+        dl = None if dl is None else dl.to(dtype).contiguous()
+        return ops.merge_cls(dg, dl, B, N, d, dtype, device)
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # generic linear (object_model.proj, txt_proj)
 # ----------------------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):

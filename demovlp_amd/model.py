@@ -113,13 +113,14 @@ class ObjectRelation(nn.Module):
         h, hr = self.text_model(input_ids=ids, attention_mask=text_data.get("attention_mask"), want_relu=True)
         lin = self.txt_proj[1]
         emb = Fn.LinearFn.apply(hr, lin.weight, lin.bias, h)      # hr = relu(h); the gradient is routed to h
-        return emb[:, 0, ...], emb[:, 1:, ...]
+        return Fn.SplitClsFn.apply(emb)                            # emb[:, 0], emb[:, 1:] (:88-90), already contiguous
 
     def compute_object(self, object_data, object_mask):
         if not object_data.is_cuda:
             raise DemoVLPHipError("ObjectRelation runs on an MI355X device only (no CPU fallback): move the batch to cuda")
         emb, add_mask = self.object_model(object_data, object_mask)
-        return emb[:, 0, ...], emb[:, 1:, ...], add_mask
+        go, lo = Fn.SplitClsFn.apply(emb)                          # emb[:, 0], emb[:, 1:] (:94-96), already contiguous
+        return go, lo, add_mask
 
     def _inflate_positional_embeds(self, new_state_dict):
         """model/model.py:98-151: adapt object_model.temporal_embed when the checkpoint's frame count differs."""

@@ -396,6 +396,22 @@ def embed_assemble(tok, box, Wp, bp, temporal, cls, pos0, mask01, B, F, R):
     return x, addmask
 
 
+def split_cls(x):
+    """x [B,N,d] (contiguous) -> (x[:, 0] as [B,d], x[:, 1:] as [B,N-1,d]), both contiguous, one launch."""
+    B, N, d = x.shape
+    g = torch.empty((B, d), device=x.device, dtype=x.dtype)
+    l = torch.empty((B, N - 1, d), device=x.device, dtype=x.dtype)
+    call("dvlp_split_cls", B, N, d * x.element_size(), p(x), p(g), p(l), stream())
+    return g, l
+
+
+def merge_cls(dg, dl, B, N, d, dtype, device):
+    """Backward of :func:`split_cls`: dx [B,N,d] from dg [B,d] / dl [B,N-1,d] (None = zeros), one launch."""
+    dx = torch.empty((B, N, d), device=device, dtype=dtype)
+    call("dvlp_merge_cls", B, N, d * dx.element_size(), p(dg), p(dl), p(dx), stream())
+    return dx
+
+
 def embed_unassemble(dx, B, F, R):
     dtok = torch.empty((B * F * R, 768), device=dx.device, dtype=dx.dtype)
     call("dvlp_embed_unassemble", dt(dx), B, F, R, p(dx), p(dtok), stream())
@@ -480,7 +496,7 @@ def global_local_loss(gt, go, xs, temperature, lam, use_global, use_local, stage
     dgt = torch.empty_like(gt) if (gt is not None and stages & 4) else None
     dgo = torch.empty_like(go) if (go is not None and stages & 4) else None
     dxs = torch.empty_like(xs) if (xs is not None and stages & 2) else None
-    losses = torch.zeros(3, device=dev, dtype=torch.float32)
+    losses = torch.empty(3, device=dev, dtype=torch.float32) if stages & 2 else None      # (all three are written by stage 2, nothing else touches them)
     d = dt(gt) if gt is not None else F32
     call("dvlp_global_local_loss", d, B, 256, p(gt), p(go), p(xs), float(temperature), float(lam), int(use_global), int(use_local),
          int(stages), p(sim), p(dsim), p(dgt), p(dgo), p(dxs), p(losses), stream())

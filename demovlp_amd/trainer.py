@@ -427,8 +427,7 @@ def backward_first(model, loss_fn, data, gather_negatives=None):
     gradients are final when this returns) and ``backward_second`` finishes it.  Returns the three detached losses."""
     text_length = torch.sum(data["text"]["attention_mask"], dim=1)
     out = model(data)
-    text_mask = data["text"]["attention_mask"][:, 1:].contiguous()
-    text_mask = (text_mask - 1.0) * 100.0
+    text_mask = (data["text"]["attention_mask"][:, 1:] - 1.0) * 100.0      # (:156-159; the subtraction already yields a contiguous tensor)
     if gather_negatives is not None:
         out, text_length, text_mask = gather_embeddings(out, text_length, text_mask, gather_negatives)
     global_sim = sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"])

@@ -149,6 +149,12 @@ int dvlp_embed_assemble(int dtype, int64_t B, int64_t F, int64_t R, const void* 
    swapped IS the time attention; the same call with F and R swapped transposes back.  F = 1 is the identity (a plain add). */
 int dvlp_token_transpose(int dtype, int64_t B, int64_t F, int64_t R, int64_t D, const void* src, const void* res, void* dst, void* stream);
 int dvlp_embed_unassemble(int dtype, int64_t B, int64_t F, int64_t R, const void* dx, void* dtok, void* stream);
+
+/* ---- the heads' view of a tower output (model/model.py:70-96: `[:, 0]` / `[:, 1:]` + .contiguous()): x [B][N][row_bytes] -> g [B][row_bytes]
+ *      (row 0 of each sample) and l [B][N-1][row_bytes] in one launch, and its backward (dx from dg / dl, NULL = zeros) in one launch.
+ *      Raw bytes, any dtype; row_bytes a multiple of 16, pointers 16-byte aligned.                                                    ---- */
+int dvlp_split_cls(int64_t B, int64_t N, int64_t row_bytes, const void* x, void* g, void* l, void* stream);
+int dvlp_merge_cls(int64_t B, int64_t N, int64_t row_bytes, const void* dg, const void* dl, void* dx, void* stream);
 int64_t dvlp_box_wgrad_chunks(int64_t M);
 int dvlp_box_wgrad(int dtype, int64_t M, const void* dtok, const float* box, float* dWp, float* workspace, int accumulate,
                    void* stream);

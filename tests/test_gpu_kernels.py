@@ -316,6 +316,26 @@ def test_loss_heads(dtype, B):
     assert float((r["dxs"] - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_split_cls_forward_and_backward_equal_the_slicing_form(dtype):
+    """SplitClsFn == (x[:, 0].contiguous(), x[:, 1:].contiguous()) and its autograd backward, bit for bit; one gradient missing -> zeros."""
+    from demovlp_amd import functional as Fn
+    B, N, d = 3, 11, 256
+    x = rnd(B * N, d, dtype=dtype).reshape(B, N, d).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    g, l = Fn.SplitClsFn.apply(x)
+    gr, lr = xr[:, 0].contiguous(), xr[:, 1:].contiguous()
+    assert g.is_contiguous() and l.is_contiguous() and torch.equal(g, gr) and torch.equal(l, lr)
+    dg, dl = rnd(B, d, dtype=dtype, seed=3), rnd(B * (N - 1), d, dtype=dtype, seed=4).reshape(B, N - 1, d)
+    torch.autograd.backward([g, l], [dg, dl])
+    torch.autograd.backward([gr, lr], [dg, dl])
+    assert torch.equal(x.grad, xr.grad)
+    x.grad = None
+    g2, l2 = Fn.SplitClsFn.apply(x)
+    l2.backward(dl)                                     # the global output unused
+    assert torch.equal(x.grad[:, 1:], dl) and float(x.grad[:, 0].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B", [32, 64])
 def test_loss_heads_matrix_core_form(B):
     """bf16, B = 32 / 64: sim_matrix and its two gradient products on the matrix cores (dsim split into two bf16 pieces) against the
