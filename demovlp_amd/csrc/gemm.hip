@@ -1364,7 +1364,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_group_kernel(P8Group g, int 
                         (int)((kend - kbeg) / H_BK), slab_out);
 }
 // sums the slabs of every split problem of a group into its fp32 destination (float4 per thread)
-struct P8GroupReduce { int count; int blk0[P8G_MAX + 1]; int S[P8G_MAX]; int64_t MN[P8G_MAX]; const float* slab[P8G_MAX]; float* C[P8G_MAX]; };
+// K tail (Kt[p] = K % 64 rows the 64-deep K tiles of the group kernel do not cover -- 32 frames x 36 regions + CLS = 1153 tokens per sample
+// make K = 16 x 1153): the rank-Kt product of the last rows rides in this pass, which already touches every output once.
+struct P8GroupReduce { int count; int blk0[P8G_MAX + 1]; int S[P8G_MAX]; int64_t MN[P8G_MAX]; const float* slab[P8G_MAX]; float* C[P8G_MAX];
+                       int Kt[P8G_MAX]; int64_t N[P8G_MAX], lda[P8G_MAX], ldb[P8G_MAX]; const bf16* tA[P8G_MAX]; const bf16* tB[P8G_MAX]; };
 __global__ __launch_bounds__(256) void p8_group_reduce_kernel(P8GroupReduce g, int accumulate) {
     int p = 0;
 #pragma unroll
@@ -1375,6 +1378,15 @@ __global__ __launch_bounds__(256) void p8_group_reduce_kernel(P8GroupReduce g, i
     for (int k = 1; k < g.S[p]; ++k) {
         const float4 v = *(const float4*)(g.slab[p] + (int64_t)k * g.MN[p] + i4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (g.Kt[p]) {
+        const int64_t m = i4 / g.N[p], n = i4 % g.N[p];          // N is a multiple of 8: the four outputs share a row
+        const bf16* ta = g.tA[p] + m; const bf16* tb = g.tB[p] + n;
+        for (int k = 0; k < g.Kt[p]; ++k) {
+            const float a = (float)ta[(int64_t)k * g.lda[p]];
+            const bf16x4 b = *(const bf16x4*)(tb + (int64_t)k * g.ldb[p]);
+            s.x += a * (float)b[0]; s.y += a * (float)b[1]; s.z += a * (float)b[2]; s.w += a * (float)b[3];
+        }
     }
     if (accumulate) {
         const float4 c = *(const float4*)(g.C[p] + i4);
@@ -1689,10 +1701,16 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
     bool group_ok = dtype == DVLP_BF16 && g_p8_mode != 0 && g_use_glds && count <= P8G_MAX && count > 1;
     int64_t T = 0;
     for (int p = 0; group_ok && p < count; ++p) {
-        group_ok = M[p] >= 256 && N[p] >= 256 && M[p] % 8 == 0 && N[p] % 8 == 0 && K[p] % H_BK == 0 && K[p] >= 1024 && ld_dy[p] % 8 == 0 &&
+        // (K need not be a multiple of the 64-deep K tile: the group covers Km = K - K % 64 rows, the slab reduction adds the rest)
+        group_ok = M[p] >= 256 && N[p] >= 256 && M[p] % 8 == 0 && N[p] % 8 == 0 && K[p] >= 1024 && ld_dy[p] % 8 == 0 &&
                    ld_x[p] % 8 == 0 && (uintptr_t)dY[p] % 16 == 0 && (uintptr_t)X[p] % 16 == 0 && (uintptr_t)dW[p] % 16 == 0;
         T += cdiv(M[p], 256) * cdiv(N[p], 256);
     }
+    int64_t Km[P8G_MAX];
+    bool tails = false;
+    for (int p = 0; group_ok && p < count; ++p) { Km[p] = K[p] - K[p] % H_BK; tails = tails || Km[p] != K[p]; }
+    // a problem with a K tail needs the slab reduction (at least two K slices): the chip-filling split below gives that when T <= 128
+    if (tails && (T > 128 || g_wgrad_split == 1)) group_ok = false;
     const WsEntry wse = ws_for(stream);
     if (!group_ok || T > 256 || !wse.ptr) {
         for (int p = 0; p < count; ++p) {
@@ -1710,7 +1728,7 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
     for (int p = 0; p < count; ++p) {
         tiles[p] = cdiv(M[p], 256) * cdiv(N[p], 256);
         S[p] = 256 / T > 0 ? 256 / T : 1;
-        if (S[p] > K[p] / 256) S[p] = K[p] / 256;
+        if (S[p] > Km[p] / 256) S[p] = Km[p] / 256;
         total += tiles[p] * S[p];
     }
     // The same K split for every problem of the group (they share K = batch x tokens): measured on MI355X, giving the CUs left over
@@ -1718,7 +1736,7 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
     // launch SLOWER -- 403 us against 309 us for a ViT layer's four products, 166 against 122 for a DistilBERT layer's -- although
     // it shortens a third of the blocks: tools/wgrad_bench.py.  g_wgrad_split > 0 forces a split (A/B measurements).
     if (g_wgrad_split > 0)
-        for (int p = 0; p < count; ++p) { S[p] = g_wgrad_split; if (S[p] > K[p] / 256) S[p] = K[p] / 256 > 0 ? K[p] / 256 : 1; }
+        for (int p = 0; p < count; ++p) { S[p] = g_wgrad_split; if (S[p] > Km[p] / 256) S[p] = Km[p] / 256 > 0 ? Km[p] / 256 : 1; }
     // slabs for every split problem must fit the split-K workspace; otherwise split less
     for (;;) {
         int64_t need = 0;
@@ -1726,25 +1744,41 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
         if (need <= wse.bytes) break;
         int worst = 0;
         for (int p = 1; p < count; ++p) if (S[p] * M[p] * N[p] > S[worst] * M[worst] * N[worst]) worst = p;
-        if (S[worst] == 1) break;
+        if (S[worst] == 1 || (tails && S[worst] == 2)) break;
         S[worst] -= 1;
+    }
+    if (tails) {
+        int64_t need = 0;
+        for (int p = 0; p < count; ++p) need += S[p] * M[p] * N[p] * 4;
+        bool ok = need <= wse.bytes;
+        for (int p = 0; p < count; ++p) ok = ok && S[p] >= 2;
+        if (!ok) {                                       // (workspace too small for two slices of everything: the one-product-at-a-time path)
+            for (int p = 0; p < count; ++p) {
+                const int rc = dvlp_gemm(dtype, 1, 1, M[p], N[p], K[p], dY[p], ld_dy[p], X[p], ld_x[p], dW[p], N[p], nullptr, nullptr, 0, nullptr, 0,
+                                         flags, 1.0f, stream);
+                if (rc != DVLP_OK) return rc;
+            }
+            return DVLP_OK;
+        }
     }
     P8GroupReduce r{};
     int blk = 0, rblk = 0, nred = 0;
     float* slab = wse.ptr;
     double flops = 0;
     for (int p = 0; p < count; ++p) {
-        const int64_t kchunk = cdiv(cdiv(K[p], S[p]), H_BK) * H_BK;
-        S[p] = cdiv(K[p], kchunk);
+        const int64_t kchunk = cdiv(cdiv(Km[p], S[p]), H_BK) * H_BK;
+        S[p] = cdiv(Km[p], kchunk);
         g.blk0[p] = blk;
         g.ntn[p] = (int)cdiv(N[p], 256); g.tiles[p] = (int)tiles[p]; g.S[p] = (int)S[p];
-        g.M[p] = M[p]; g.N[p] = N[p]; g.K[p] = K[p]; g.lda[p] = ld_dy[p]; g.ldb[p] = ld_x[p]; g.kchunk[p] = kchunk;
+        g.M[p] = M[p]; g.N[p] = N[p]; g.K[p] = Km[p]; g.lda[p] = ld_dy[p]; g.ldb[p] = ld_x[p]; g.kchunk[p] = kchunk;
         g.A[p] = (const bf16*)dY[p]; g.B[p] = (const bf16*)X[p]; g.C[p] = (float*)dW[p];
         g.slab[p] = S[p] > 1 ? slab : nullptr;
         blk += (int)((tiles[p] * S[p] + 7) / 8 * 8);
         flops += 2.0 * M[p] * N[p] * K[p];
         if (S[p] > 1) {
             r.blk0[nred] = rblk; r.S[nred] = (int)S[p]; r.MN[nred] = M[p] * N[p]; r.slab[nred] = slab; r.C[nred] = (float*)dW[p];
+            r.Kt[nred] = (int)(K[p] - Km[p]); r.N[nred] = N[p]; r.lda[nred] = ld_dy[p]; r.ldb[nred] = ld_x[p];
+            r.tA[nred] = (const bf16*)dY[p] + Km[p] * ld_dy[p]; r.tB[nred] = (const bf16*)X[p] + Km[p] * ld_x[p];
             rblk += (int)cdiv(M[p] * N[p], 1024);
             slab += S[p] * M[p] * N[p];
             ++nred;

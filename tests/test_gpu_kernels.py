@@ -464,10 +464,12 @@ def test_deferred_reductions_match_immediate():
     assert torch.equal(cs, ops.colsum(dx0))
 
 
+@pytest.mark.parametrize("T", [4160, 4624 + 16, 18448], ids=["tokens-64k", "tokens-64k+16", "tokens-16x1153"])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_wgrad_grouped_matches_single(dtype):
-    """dvlp_wgrad_grouped (one grouped 256x256 launch + one slab reduction in bf16) against per-problem dW GEMMs and fp32 torch."""
-    T = 4160
+def test_wgrad_grouped_matches_single(dtype, T):
+    """dvlp_wgrad_grouped (one grouped 256x256 launch + one slab reduction in bf16) against per-problem dW GEMMs and fp32 torch.
+    Token counts that are not a multiple of the 64-deep K tile (16 x 1153 = the 32-frame batch): the last rows' product rides in
+    the slab reduction."""
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (256, 768), (768, 264)]
     probs, refs = [], []
     for i, (N, K) in enumerate(shapes):
