@@ -134,7 +134,7 @@ if os.path.exists(f32):
     if l32:
         open(os.path.join(P, tag + "_bench_f32_b16.json"), "w").write(l32[-1])
 for extra in ("select_bench.txt", "select_bench_f32.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt",
-              "input_bench.txt", "eval_bench.txt", "tile_height_bench.txt", "attn_bench.txt"):
+              "input_bench.txt", "eval_bench.txt", "tile_height_bench.txt", "attn_bench.txt", "loss_head_bench.txt", "step_timeline.txt"):
     src = os.path.join(SRC, extra)
     if os.path.exists(src):
         keep = [l for l in open(src) if "amdgpu.ids" not in l]

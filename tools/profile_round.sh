@@ -30,6 +30,9 @@ timeout 300 python3 $R/tools/input_bench.py > $O/input_bench.txt 2>&1
 timeout 900 python3 $R/tools/eval_bench.py --pairs 1000 > $O/eval_bench.txt 2>&1
 timeout 300 python3 $R/tools/tile_height_bench.py > $O/tile_height_bench.txt 2>&1
 timeout 300 python3 $R/tools/attn_bench.py > $O/attn_bench.txt 2>&1
+timeout 300 python3 $R/tools/loss_head_bench.py > $O/loss_head_bench.txt 2>&1
+# where one replayed step's time goes between the kernels (device-idle gaps, launches under 10 us) -- from the kernel trace above
+python3 $R/tools/step_timeline.py $(find $O/trace -name "*kernel_trace.csv" | head -1) 2 > $O/step_timeline.txt 2>&1
 # keep what travels back small: the per-dispatch traces are large
 for d in trace fetch write mfma; do find $O/$d -name "*kernel_trace.csv" -size +20M -delete; done
 ls -la $O $O/trace $O/fetch $O/write $O/mfma
