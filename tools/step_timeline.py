@@ -10,7 +10,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 2
 marks = [i for i, r in enumerate(rows) if "obj_split" in r["Kernel_Name"]]
-a, b = marks[-back - 1], marks[-back]
+# whole steps only (bench.py also times the object tower alone at the end): segments that contain the local loss' backward
+full = [(a, b) for a, b in zip(marks, marks[1:]) if any("xsoftmax_bwd" in r["Kernel_Name"] for r in rows[a:b])]
+# ... and, where there are any, the graph-replayed ones (text tower on its own queue; bench.py's eager timing region runs on one)
+multi = [(a, b) for a, b in full if len({r["Queue_Id"] for r in rows[a:b]}) > 1]
+a, b = (multi or full)[-min(back, len(multi or full))]
 seg = rows[a:b]
 t0 = int(seg[0]["Start_Timestamp"])
 span = (int(rows[b]["Start_Timestamp"]) - t0) / 1e3
@@ -30,7 +34,7 @@ for s, e in iv:
 print(f"device idle inside the step: {idle:.1f} us in {len(gaps)} gaps; gaps > 2 us:")
 byname = {int(r["Start_Timestamp"]): r["Kernel_Name"] for r in seg}
 starts = sorted(byname)
-for at, g in gaps:
+for at, g in sorted(gaps, key=lambda x: -x[1])[:25]:
     if g > 2.0:
         nxt = next((byname[s] for s in starts if (s - t0) / 1e3 >= at + g - 0.01), "?")
         print(f"   t = {at:9.1f} us  gap {g:6.1f} us  before {nxt[:70]}")
