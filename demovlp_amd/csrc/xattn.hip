@@ -608,6 +608,11 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
     if (a.stop == 6) { if (d1p[0][0] == 0x12345678u) rn[0] = 1.f; return; }          // timing ablation: launch + dP1 rows only
     pair_load_S<bf16>(a, i, j, Ssm, rn, cn, cpart);
     if (a.stop == 1 || a.stop == 5) { if (d1p[0][0] == 0x12345678u) rn[0] = 1.f; return; }
+    // Gram form: the (alpha, beta) pairs of this pair's regions go to LDS once (the column-norm partials' space is free now) -- read per
+    // row from global memory, each was a full round trip the text->image pass waited for (s_waitcnt vmcnt(0) ten times per wave)
+    const bool ab_lds = gram && 2 * a.G <= 8 * a.W;
+    if (ab_lds)
+        for (int t = threadIdx.x; t < 2 * a.G; t += XT) cpart[t] = ab[t];
     const float* mimg = a.mimg + (int64_t)i * a.G;
     const float* mcap = a.mcap + (int64_t)j * a.W;
     float d2v[IT2][NKW];                        // dA2 c of the rows this half owns, for the last pass
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
     }
     {
         constexpr int W32 = 32 * NKW;
-        float mc[NKW], ci2[NKW], cd[NKW];
+        float mc[NKW], ci2[NKW], cd[NKW];       // ci2 = c lambda log2 e: lambda c = ci2 ln 2 (hoisting the product costs four live registers: spills)
         int wo[NKW];
 #pragma unroll
         for (int k = 0; k < NKW; ++k) {
@@ -681,6 +686,7 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
             mc[k] = w < a.W ? mcap[w] * l2 - sh : -INFINITY; ci2[k] = w < a.W ? cn[w] * l2 : 0.f; cd[k] = 0.f;
         }
         const float inv_W = 1.f / (float)a.W;
+        if (ab_lds) __syncthreads();                 // (wave-uniform) the staged (alpha, beta) pairs
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
             const int g = 2 * wid + half + 2 * NW * it;
@@ -694,13 +700,39 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
                 e[k] = fmaf(sv[k], ci2[k], mc[k]);
             }
             focal_softmax_fast<NKW, false, true>(e, pp, inv_W, a.gate, s);
-            float dpp[NKW], d1 = 0.f;
             float alpha = 0.f, beta = 0.f;
-            if (gram) { alpha = ab[2 * gc]; beta = ab[2 * gc + 1]; }
+            if (gram) {
+                if (ab_lds) { const float2 t2 = *(const float2*)&cpart[2 * gc]; alpha = t2.x; beta = t2.y; }
+                else { alpha = ab[2 * gc]; beta = ab[2 * gc + 1]; }
+                // u depends on S_raw directly: dS_raw += alpha P2 (scaled by 1 / LeakyReLU' so that the last pass' factor leaves it as it is;
+                // rows past the last region are never read back), and beta P2 replaces T for the dKq product.  P' as stored (bf16), once:
+                // pairs packed by one v_cvt_pk_bf16_f32, widened by shifts -- consumed here, before the gradient chain needs the registers
+                bf16* Trow = (bf16*)a.T + (((int64_t)j * a.Bi + i) * a.G + g) * a.Wp;
+#pragma unroll
+                for (int k = 0; k < NKW; k += 2) {
+                    const bf16 two[2] = {(bf16)pp[k], (bf16)(k + 1 < NKW ? pp[k + 1] : 0.f)};
+                    const uint32_t u = *(const uint32_t*)two;
+                    const float p0 = __uint_as_float(u << 16), p1 = __uint_as_float(u & 0xffff0000u);
+                    d2v[it][k] = alpha * (sv[k] > 0.f ? 1.f : 10.f) * p0;
+                    if (k + 1 < NKW) d2v[it][k + 1] = alpha * (sv[k + 1] > 0.f ? 1.f : 10.f) * p1;
+                    if constexpr (PAIR) {
+                        const int w = wslot<true>(hl, k);                // pp is zero past the last word: the pad column stays zero
+                        if (ok && w < a.W) { const bf16 b2[2] = {(bf16)(beta * p0), (bf16)(beta * p1)}; *(uint32_t*)(Trow + w) = *(const uint32_t*)b2; }
+                    } else {
+                        const int w = hl + 32 * k;
+                        if (ok && w < a.W) Trow[w] = (bf16)(beta * p0);
+                        if (k + 1 < NKW && ok && w + 32 < a.W) Trow[w + 32] = (bf16)(beta * p1);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NKW; ++k) d2v[it][k] = 0.f;
+            }
+            float dpp[NKW], d1 = 0.f;
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
                 dpp[k] = unpack(d2p[it], k);
-                if (gram) dpp[k] = alpha * fminf(sv[k], 10.f * sv[k]) - beta * dpp[k];      // dP2 = alpha S_raw - beta (P2 Kq); S_raw = min(s, 10 s) undoes LeakyReLU_0.1
+                if (gram) dpp[k] = alpha * (sv[k] * (sv[k] > 0.f ? 1.f : 10.f)) - beta * dpp[k];  // dP2 = alpha S_raw - beta (P2 Kq); S_raw = s / LeakyReLU'
                 d1 += dpp[k] * pp[k];
             }
             d1 = half_sum(d1);
@@ -712,30 +744,8 @@ __global__ __launch_bounds__(XT) void xsoftmax_bwd_bf16_kernel(PairArgs a) {
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
                 const float t = ok ? e[k] * (dpp[k] - d2) : 0.f;         // dA = lambda t; lambda c = ci2 ln 2
-                d2v[it][k] = t * (ci2[k] * XLN2);
+                d2v[it][k] = fmaf(t, ci2[k] * XLN2, d2v[it][k]);
                 cd[k] += t * sv[k];
-                if (gram) {
-                    // u depends on S_raw directly: dS_raw += alpha P2 (scaled so that the LeakyReLU' factor of the last pass leaves it as it
-                    // is), and beta P2 replaces T for the dKq product
-                    const float pk = (float)(bf16)pp[k];
-                    if (ok) d2v[it][k] += alpha * pk * (sv[k] > 0.f ? 1.f : 10.f);
-                    if constexpr (!PAIR) {
-                        const int w = hl + 32 * k;
-                        if (ok && w < a.W) ((bf16*)a.T)[(((int64_t)j * a.Bi + i) * a.G + g) * a.Wp + w] = (bf16)(beta * pk);
-                    }
-                }
-            }
-            if constexpr (PAIR) {
-                if (gram && ok) {
-#pragma unroll
-                    for (int k = 0; k < NKW; k += 2) {
-                        const int w = wslot<true>(hl, k);                // pp is zero past the last word: the pad column stays zero
-                        if (w < a.W) {
-                            const bf16 two[2] = {(bf16)(beta * (float)(bf16)pp[k]), (bf16)(beta * (float)(bf16)pp[k + 1])};
-                            *(uint32_t*)((bf16*)a.T + (((int64_t)j * a.Bi + i) * a.G + g) * a.Wp + w) = *(const uint32_t*)two;
-                        }
-                    }
-                }
             }
         }
 #pragma unroll
