@@ -287,11 +287,17 @@ extern "C" int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x
 #include <mutex>
 #include <vector>
 struct RItem { const float* in; float* out; int64_t P, C, stride; int accumulate; int blk0; };
+// The items travel to the kernel BY VALUE, a batch per launch (kernel arguments are part of a captured graph node): a device-side table
+// would be shared by every captured graph and every eager step -- a step of another shape rewrites it under the graphs that point at
+// it -- and uploading it needs a copy and a stream synchronisation, neither of which may happen during a capture.
+struct RItemC { const float* in; float* out; int P, C, stride, blk0acc; };      // 32 bytes; blk0acc = 2 * (first block within the batch) + accumulate
+constexpr int RB_MAX = 96;
+struct RBatch { int n, pad; RItemC it[RB_MAX]; };                               // 3 080 bytes of kernel arguments
 struct RDefer {
     std::mutex mu;
     float* ws = nullptr; int64_t ws_floats = 0, used = 0;
-    RItem* d_items = nullptr; int64_t cap_items = 0;
-    std::vector<RItem> cur, uploaded;
+    int64_t cap_items = 0;
+    std::vector<RItem> cur;
     int nblk = 0;
 };
 static RDefer g_rd;
@@ -299,8 +305,9 @@ static RDefer g_rd;
 extern "C" int dvlp_reduce_defer(void* workspace, int64_t workspace_bytes, void* table, int64_t table_bytes) {
     std::lock_guard<std::mutex> lk(g_rd.mu);
     g_rd.ws = (float*)workspace; g_rd.ws_floats = workspace ? workspace_bytes / 4 : 0; g_rd.used = 0;
-    g_rd.d_items = (RItem*)table; g_rd.cap_items = table ? table_bytes / (int64_t)sizeof(RItem) : 0;
-    g_rd.cur.clear(); g_rd.uploaded.clear(); g_rd.nblk = 0;
+    (void)table;                                         // (a device-side item table is no longer used: see RBatch)
+    g_rd.cap_items = workspace ? (table_bytes > 0 ? table_bytes / 48 : 4096) : 0;      // bound on the queue length, as the caller sized it
+    g_rd.cur.clear(); g_rd.nblk = 0;
     return DVLP_OK;
 }
 // reserve `floats` of partial space for a deferrable call; nullptr: not enabled / full -> the caller reduces immediately
@@ -323,36 +330,39 @@ float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void reduce_batched_kernel(const RItem* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256) void reduce_batched_kernel(const RBatch b) {
     __shared__ float red[4][64];
-    // which item owns this block: binary search over the items' first-block prefix (<= ~10 steps, wave-uniform)
-    int lo = 0, hi = nitems - 1;
+    // which item owns this block: binary search over the items' first-block prefix (<= 7 steps, wave-uniform, scalar loads of the arguments)
+    int lo = 0, hi = b.n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if ((b.it[mid].blk0acc >> 1) <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const RItem it = items[lo];
+    const float* __restrict__ in = b.it[lo].in;
+    float* __restrict__ out = b.it[lo].out;
+    const int P = b.it[lo].P, C = b.it[lo].C, blk0 = b.it[lo].blk0acc >> 1, accumulate = b.it[lo].blk0acc & 1;
+    const int64_t stride = b.it[lo].stride;
     // 64 columns (a 256-byte piece of each partial row) x 4 row slices per workgroup
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t c = (int64_t)(blockIdx.x - it.blk0) * 64 + cl;
+    const int64_t c = (int64_t)((int)blockIdx.x - blk0) * 64 + cl;
     float s = 0.f;
-    if (c < it.C) {
+    if (c < C) {
         // eight independent partial rows in flight per thread (a plain loop was one dependent load after another: 144 us for the step's
         // ~130 queued reductions, most of them 1024 LayerNorm partial rows deep)
         float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int64_t p = q;
-        for (; p + 28 < it.P; p += 32) {
+        for (; p + 28 < P; p += 32) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += it.in[(p + 4 * u) * it.stride + c];
+            for (int u = 0; u < 8; ++u) s8[u] += in[(p + 4 * u) * stride + c];
         }
-        for (; p < it.P; p += 4) s8[0] += it.in[p * it.stride + c];
+        for (; p < P; p += 4) s8[0] += in[p * stride + c];
         s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     red[q][cl] = s;
     __syncthreads();
-    if (q == 0 && c < it.C) {
+    if (q == 0 && c < C) {
         const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        it.out[c] = it.accumulate ? it.out[c] + t : t;
+        out[c] = accumulate ? out[c] + t : t;
     }
 }
 
@@ -361,19 +371,21 @@ extern "C" int dvlp_reduce_flush(void* stream) {
     if (g_rd.cur.empty()) { g_rd.used = 0; return DVLP_OK; }
     dvlp_clear_status();
     hipStream_t st = (hipStream_t)stream;
-    // the queue of a training step repeats exactly (same arena offsets, same destinations): upload the table only when it changed
-    bool same = g_rd.cur.size() == g_rd.uploaded.size();
-    for (size_t i = 0; same && i < g_rd.cur.size(); ++i) {
-        const RItem &a = g_rd.cur[i], &b = g_rd.uploaded[i];
-        same = a.in == b.in && a.out == b.out && a.P == b.P && a.C == b.C && a.stride == b.stride && a.accumulate == b.accumulate && a.blk0 == b.blk0;
+    // batches of up to RB_MAX items, each one launch with its items in the kernel arguments (a training step queues ~130: two launches)
+    for (size_t i0 = 0; i0 < g_rd.cur.size(); i0 += RB_MAX) {
+        RBatch b{};
+        const size_t n = g_rd.cur.size() - i0 < (size_t)RB_MAX ? g_rd.cur.size() - i0 : (size_t)RB_MAX;
+        const int base = g_rd.cur[i0].blk0;
+        int nblk = 0;
+        b.n = (int)n;
+        for (size_t k = 0; k < n; ++k) {
+            const RItem& r = g_rd.cur[i0 + k];
+            if (r.P > INT32_MAX || r.C > INT32_MAX || r.stride > INT32_MAX) return DVLP_ERR_SHAPE;
+            b.it[k] = RItemC{r.in, r.out, (int)r.P, (int)r.C, (int)r.stride, 2 * (r.blk0 - base) + (r.accumulate ? 1 : 0)};
+            nblk = r.blk0 - base + (int)cdiv(r.C, 64);
+        }
+        hipLaunchKernelGGL(reduce_batched_kernel, dim3((unsigned)nblk), dim3(256), 0, st, b);
     }
-    if (!same) {
-        // the previous table may still be read by an earlier flush on this stream: the copy is stream-ordered behind it
-        if (hipMemcpyAsync(g_rd.d_items, g_rd.cur.data(), g_rd.cur.size() * sizeof(RItem), hipMemcpyHostToDevice, st) != hipSuccess) return DVLP_ERR_LAUNCH;
-        (void)hipStreamSynchronize(st);          // the host vector is reused right away
-        g_rd.uploaded = g_rd.cur;
-    }
-    hipLaunchKernelGGL(reduce_batched_kernel, dim3((unsigned)g_rd.nblk), dim3(256), 0, st, (const RItem*)g_rd.d_items, (int)g_rd.cur.size());
     g_rd.cur.clear(); g_rd.used = 0; g_rd.nblk = 0;
     return dvlp_launch_status();
 }

@@ -169,9 +169,14 @@ def _workspace(key, nfloat, device):
     k = (key, device, torch.cuda.current_stream().cuda_stream)
     t = _WS.get(k)
     if t is None or t.numel() < nfloat:
+        if t is not None:
+            _WS_RETIRED.append(t)       # a captured graph may still point at the smaller buffer: it must never be handed to anyone else
         t = torch.empty(int(nfloat), device=device, dtype=torch.float32)
         _WS[k] = t
     return t
+
+
+_WS_RETIRED = []
 
 
 _COLSUM_CNT = {}

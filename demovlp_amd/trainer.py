@@ -511,7 +511,8 @@ class GraphedTrainStep:
     every run is all-reduced in ``bucket_mb`` pieces on the communication stream while the NEXT graph runs, and each piece is
     handed to the fused optimizer on a third stream the moment its reduction completes (``adamw_range_dev``; the 1 / world average
     is folded into its grad_scale), so neither the optimizer nor any exchange but the last piece's (blocks 0-3 + prologue: ~20 % of
-    the bytes at the default cuts) waits for the whole arena.  Static shapes only: a batch of another shape re-captures."""
+    the bytes at the default cuts) waits for the whole arena.  One captured set per batch shape (up to ``max_shapes``): a batch of another
+    shape -- a loader's smaller last batch -- runs ``warmup`` eager steps of its own, is captured, and from then on both shapes replay."""
 
     def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 64.0, always_reduce: bool = False,
                  cut=(8, 4)):
@@ -523,6 +524,9 @@ class GraphedTrainStep:
         # always_reduce: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
         self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
         self.graphs, self.static, self.out, self.shape_key = None, None, None, None
+        # one captured set per batch shape (a loader's last batch is smaller; evaluation-sized batches come and go): shape key ->
+        # (graphs, input buffers, output tensors), plus the calls seen per shape -- every shape gets its own eager warm-up before its capture
+        self._sets, self._seen, self.max_shapes = {}, {}, 4
         self.cuts, self.piece_runs, self._comm, self._optst = (), [[(0, optimizer.arena.total)]], None, None
         om = getattr(model, "object_model", None)
         if self.collective and cut and om is not None and hasattr(om, "grad_cut"):
@@ -696,8 +700,8 @@ class GraphedTrainStep:
 
     @property
     def inputs(self):
-        """The captured graphs' input buffers ``{'text': {input_ids, attention_mask}, 'object', 'object_mask'}`` (None before the
-        capture).  A loader that writes a batch straight into them -- ``RegionBatcher.to_device(out=step.inputs)``, the selection
+        """The input buffers ``{'text': {input_ids, attention_mask}, 'object', 'object_mask'}`` of the captured set used last (None
+        before the first capture; a batch of another shape has its own set, with its own buffers, once it has been captured).  A loader that writes a batch straight into them -- ``RegionBatcher.to_device(out=step.inputs)``, the selection
         kernel's output IS the model's input -- and hands the same dict to ``__call__`` saves the device-to-device copy of the batch
         (151 MB of region features at B = 64: ~65 us a step).  Write into them only from the thread / stream that replays the graphs:
         stream order is what keeps batch n+1 from landing before step n has read batch n."""
@@ -725,11 +729,22 @@ class GraphedTrainStep:
 
     def __call__(self, data):
         self.calls += 1
-        if self.graphs is None or self._key(data) != self.shape_key:
-            if self.calls <= self.warmup:
+        key = self._key(data)
+        have = self._sets.get(key)
+        if have is None:
+            n = self._seen.get(key, 0) + 1
+            self._seen[key] = n
+            if n <= self.warmup:
+                # a shape's first calls run eagerly: kernel attributes, workspaces and every other first-use side effect that may not
+                # happen inside a capture are behind it when the capture comes
                 return self._eager(data)
+            if len(self._sets) >= self.max_shapes:
+                self._sets.pop(next(iter(self._sets)))        # oldest capture (its memory pool goes with it)
             self._capture(data)
+            self._sets[key] = (self.graphs, self.static, self.out)
         else:
+            self.graphs, self.static, self.out = have
+            self.shape_key = key
             for k, v in data["text"].items():
                 self._put(self.static["text"][k], v)
             self._put(self.static["object"], data["object"])
