@@ -701,10 +701,11 @@ class GraphedTrainStep:
     @property
     def inputs(self):
         """The input buffers ``{'text': {input_ids, attention_mask}, 'object', 'object_mask'}`` of the captured set used last (None
-        before the first capture; a batch of another shape has its own set, with its own buffers, once it has been captured).  A loader that writes a batch straight into them -- ``RegionBatcher.to_device(out=step.inputs)``, the selection
-        kernel's output IS the model's input -- and hands the same dict to ``__call__`` saves the device-to-device copy of the batch
-        (151 MB of region features at B = 64: ~65 us a step).  Write into them only from the thread / stream that replays the graphs:
-        stream order is what keeps batch n+1 from landing before step n has read batch n."""
+        before the first capture; a batch of another shape has its own set, with its own buffers, once it has been captured).
+        A loader that writes a batch straight into them -- ``RegionBatcher.to_device(out=step.inputs)``: the selection kernel's
+        output IS the model's input -- and hands the same dict to ``__call__`` saves the device-to-device copy of the batch (151 MB
+        of region features at B = 64: ~65 us a step).  Write into them only from the thread / stream that replays the graphs:
+        stream order is what keeps batch n + 1 from landing before step n has read batch n."""
         return self.static if self.graphs is not None else None
 
     @staticmethod
