@@ -185,9 +185,9 @@ def prefetching(batches: Iterable, depth: int = 2, device=None) -> Iterator:
     base/base_data_loader.py:23-38).
 
     The worker thread adopts the CALLER's current device (or ``device``): a fresh thread starts on device 0 regardless of the
-    ``torch.cuda.set_device(LOCAL_RANK)`` the main thread did.  The worker allocates, copies and launches, so it must not run while
-    a hipGraph is being captured in 'global' error mode (``GraphedTrainStep`` captures on its third call): start it after the
-    capturing step, or capture with ``capture_error_mode='thread_local'``."""
+    ``torch.cuda.set_device(LOCAL_RANK)`` the main thread did.  The worker allocates, copies and launches, which would invalidate a
+    hipGraph capture running in 'global' error mode on another thread: ``GraphedTrainStep`` therefore captures with
+    ``capture_error_mode='thread_local'`` (its captures come whenever a new batch shape has been seen three times, mid-epoch included)."""
     import queue
     import threading
     q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))

@@ -722,7 +722,8 @@ class GraphedTrainStep:
         self.graphs = []
         for k in range(len(self.cuts) + 1):                 # graphs sharing one memory pool: each consumes what the previous ones saved
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **({"pool": self.graphs[0].pool()} if self.graphs else {})):
+            # thread_local: a loader thread (data.prefetching) keeps staging, copying and waiting on events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local", **({"pool": self.graphs[0].pool()} if self.graphs else {})):
                 self._piece(k, self.static)
             self.graphs.append(g)
         if not self.collective:

@@ -700,9 +700,12 @@ def test_graph_step_recaptures_when_the_batch_shape_changes():
     #  is a float atomic sum of three addends, whose order is not fixed from run to run; two-sample batches elsewhere compare bit for bit)
     for a, b in zip(losses[0], losses[1]):
         assert abs(a - b) <= 1e-5 * abs(a), (losses[0], losses[1])
-    # two EAGER runs of this sequence differ by up to ~4e-6 in a parameter for that reason; a missed or doubled step, or a reduction reading
-    # another shape's table, moves parameters by the learning rate (1e-4) per step
-    assert float((finals[0] - finals[1]).abs().max()) < 2e-5
+    # One step's gradients repeat to ~3e-8 absolute; AdamW divides by sqrt(v) + 1e-6, so an element whose gradient is below 1e-6 turns that
+    # into a few % of the learning rate per step: two EAGER runs of this sequence differ by up to ~1.3e-4 in a handful of the 153 M
+    # parameters.  A missed or doubled step, or a reduction reading another shape's table, moves EVERY parameter by ~lr = 1e-4.
+    d = (finals[0] - finals[1]).abs()
+    assert float((d > 2e-5).float().mean()) < 1e-4, (float(d.max()), int((d > 2e-5).sum()))
+    assert float(d.max()) < 5e-4
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
@@ -735,3 +738,35 @@ def test_evaluation_between_replayed_steps_leaves_training_unchanged(dtype):
     # (the fused per-pair evaluation kernel of the bf16 path is not bit-reproducible from launch to launch: see the precision-knob test)
     assert abs(vals[0]["val_loss"] - vals[1]["val_loss"]) < 1e-5 * abs(vals[0]["val_loss"])
     assert np.allclose(vals[0]["o2t_sims"], vals[1]["o2t_sims"], rtol=1e-5, atol=1e-6)
+
+
+def test_graph_capture_with_a_prefetching_loader_thread_running():
+    """the loader thread stages, copies and waits on events while the step is being captured (and, with one captured
+    set per shape, a capture can now come at any point of an epoch).  The capture must not be invalidated by that thread's HIP calls, and
+    the steps must equal the same batches fed without a thread."""
+    from demovlp_amd import functional as Fn
+    from demovlp_amd.data import RegionBatcher, prefetching
+    F, R, B, NRAW, STEPS = 8, 36, 2, 40, 7
+    ids, att = syn.caption_batch(B, first_sample=0)
+    text = {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(att).to(DEV)}
+
+    def batches(rb):
+        for k in range(STEPS):
+            for b in range(B):
+                for f in range(F):
+                    fr = syn.make_frame(50 + 5 * k + b, f, NRAW)
+                    rb.stage(b, f, fr["x"], fr["bbox"], fr["objects_conf"], (640.0, 360.0))
+            obj, mask, _ = rb.to_device()
+            yield {"text": text, "object": obj, "object_mask": mask}
+
+    losses = []
+    for threaded in (False, True):
+        Fn.SHADOWS.clear()
+        model = build(F, R)
+        opt = FusedAdamW(ParamArena(model), lr=1e-4)
+        step = GraphedTrainStep(model, loss_head(), opt, warmup=2)
+        rb = RegionBatcher(B, F, R, max_regions=64, device=DEV)
+        it = prefetching(batches(rb), depth=3) if threaded else batches(rb)
+        losses.append([float(step(d)[0]) for d in it])
+        torch.cuda.synchronize()
+    assert losses[0] == losses[1], (losses[0], losses[1])
