@@ -187,13 +187,101 @@ __global__ __launch_bounds__(256) void text_embed_kernel(int64_t M, int L, const
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
-// dword[id] += de[row] (padding_idx 0 gets no gradient); float atomics (only [CLS]/[SEP] rows collide)
+// dword[id] += sum of de[row] over the rows holding token id (padding_idx 0 gets no gradient), WITHOUT float atomics: the first row that
+// holds an id (its "leader") sums every row of that id in index order and is the only writer of dword[id] -- [CLS] / [SEP] sit in every
+// caption, and an atomic sum of B addends is not reproducible from run to run (AdamW's 1e-6 epsilon turns that ulp-level noise into a few
+// per cent of the learning rate for small gradients).  This was the only float atomic of the training step: steps are now bit-reproducible.
 template <typename T>
-__global__ void text_embed_bwd_kernel(int64_t M, const int64_t* __restrict__ ids, const T* __restrict__ de, float* __restrict__ dword) {
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(int64_t M, const int64_t* __restrict__ ids, const T* __restrict__ de, float* __restrict__ dword) {
+    constexpr int LIST = 1024;                  // member rows gathered per round (a token in more than 1024 rows takes several rounds)
+    constexpr int NV = EMB / 256;               // 4-column pieces per lane: a WAVE covers a whole row
+    __shared__ int list[LIST];
+    __shared__ int wsum[4];
+    __shared__ float part[3][EMB];
     const int64_t row = blockIdx.x;
     const int64_t id = ids[row];
     if (id == 0) return;
-    for (int d = threadIdx.x; d < EMB; d += blockDim.x) atomicAdd(dword + id * EMB + d, to_f(de[row * EMB + d]));
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // pass 1, every candidate: is an earlier row holding this token (then its leader sums this row too), is a later one (coalesced, no order)
+    int earlier = 0, later = 0;
+    unsigned long long smask = 0ull;                 // bit k: position tid + 256 k holds this token (first 64 tiles; beyond: re-read in pass 2)
+    for (int64_t k0 = 0; k0 * 256 < M; k0 += 8) {         // eight independent loads in flight (one by one each paid an L2 round trip)
+        int64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t m = (k0 + u) * 256 + tid; v[u] = m < M ? ids[m] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t k = k0 + u, m = k * 256 + tid;
+            const bool same = v[u] == id;
+            earlier |= (same && m < row);
+            later |= (same && m > row);
+            if (same && k < 64) smask |= 1ull << k;
+        }
+    }
+    if (__syncthreads_or(earlier)) return;
+    const bool dup = __syncthreads_or(later);
+    // wave w sums the members of rank = w (mod 4) in rank order (the leader row itself is wave 0's first addend); the four partial rows are
+    // then added in wave order: one fixed association, whatever the launch looks like
+    float acc[NV][4];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        if (wid == 0) ld4(de + row * EMB + q * 256 + lane * 4, acc[q]);
+        else { acc[q][0] = 0.f; acc[q][1] = 0.f; acc[q][2] = 0.f; acc[q][3] = 0.f; }
+    }
+    // pass 2, the few leaders of repeated tokens: the later rows in index order, 256 candidate positions at a time (ballot per wave + wave
+    // offsets), LIST of them per round
+    for (int first = 0, more = dup ? 1 : 0; more; first += LIST) {
+        int cnt = 0;                                 // rank of the next hit (uniform)
+        // tiles aligned with pass 1 (position = tid + 256 k): the compare results are in `smask`, so a tile costs no memory round trip
+        for (int64_t k = row >> 8; k * 256 < M; ++k) {
+            const int64_t m = k * 256 + tid;
+            const bool hit = m > row && m < M && (k < 64 ? ((smask >> k) & 1ull) != 0ull : ids[m] == id);
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wsum[wid] = __popcll(bal);
+            __syncthreads();
+            int off = cnt, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { if (w < wid) off += wsum[w]; tot += wsum[w]; }
+            const int r = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && r >= first && r < first + LIST) list[r - first] = (int)m;
+            cnt += tot;
+            __syncthreads();
+        }
+        const int n = cnt - first < LIST ? cnt - first : LIST;
+        more = cnt > first + LIST;
+#pragma unroll 4
+        for (int k = wid; k < n; k += 4) {
+            const int64_t m = list[k];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                float v[4];
+                ld4(de + m * EMB + q * 256 + lane * 4, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q][j] += v[j];
+            }
+        }
+        __syncthreads();
+    }
+    if (wid > 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) *(float4*)&part[wid - 1][q * 256 + lane * 4] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            float4* dst = (float4*)(dword + id * EMB + q * 256 + lane * 4);
+            float4 o = *dst;
+            float s4[4] = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 p4 = *(const float4*)&part[w][q * 256 + lane * 4];
+                s4[0] += p4.x; s4[1] += p4.y; s4[2] += p4.z; s4[3] += p4.w;
+            }
+            o.x += s4[0]; o.y += s4[1]; o.z += s4[2]; o.w += s4[3];
+            *dst = o;
+        }
+    }
 }
 
 template <typename S, typename D>
