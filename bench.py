@@ -159,7 +159,7 @@ def time_object_tower(model, data, steps, dist_sync, graph=True):
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.graph_capture(g):
                 one()
             g.replay()
             torch.cuda.synchronize()

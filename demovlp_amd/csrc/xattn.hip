@@ -1181,6 +1181,10 @@ __global__ __launch_bounds__(256) void xgram_v_kernel(int64_t rows, int Wp, cons
     if (r < rows && sub == 0) { st2[r * 2] = u2[r]; st2[r * 2 + 1] = sqrtf(fmaxf(q, 0.f)); }
 }
 // backward of the cosine for the Gram form: st2 (u, |wc2|) -> (alpha, beta) per (j, i, g) row
+__global__ __launch_bounds__(256) void xzero_kernel(float4* __restrict__ p, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 __global__ __launch_bounds__(256) void xgram_ab_kernel(int Bi, int Bj, int G, const float* __restrict__ dscores, const float* __restrict__ nc, float* __restrict__ st2) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (j * Bi + i) * G + g
     if (r >= (int64_t)Bj * Bi * G) return;
@@ -1418,7 +1422,10 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
         // the normalisation's backward removes), so the direct-term buffer is zero
         hipLaunchKernelGGL(xgram_ab_kernel, dim3((unsigned)cdiv(Bj * Bi * G, 256)), b256, 0, s2, (int)Bi, (int)Bj, (int)G, dscores,
                            (const float*)(ws + L.off_nc), (float*)(ws + L.off_st2));
-        (void)hipMemsetAsync(dirc, 0, (size_t)Bi * G * XD * 4, s2);
+        // (a kernel, not hipMemsetAsync: captured into a hipGraph the memset node was not reliably ordered against its neighbours when a
+        //  replay started on an idle device -- xprep_bwd then read whatever the region held before, and the video-side gradients of that
+        //  step were garbage; tests/test_gpu_round3.py: replays with a host synchronisation between them)
+        hipLaunchKernelGGL(xzero_kernel, dim3((unsigned)cdiv(Bi * G * XD / 4, 256)), b256, 0, s2, (float4*)dirc, (int64_t)(Bi * G * XD / 4));
     }
     // dP1[i] [(Bj*Wp) x G] = dwc[i] [(Bj*Wp) x d] . Chat_i^T
     const bool pairg = x_pairg(dtype, G, W);          // columns of dP1 in xperm_g order: the product takes Chat's rows in that order

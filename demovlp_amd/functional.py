@@ -98,10 +98,21 @@ def join_side_stream():
     if not torch.cuda.is_available():
         return
     cur = torch.cuda.current_stream()
-    if OVERLAP_WGRAD:
+    capturing = torch.cuda.is_current_stream_capturing()
+
+    def joinable(s):
+        # While a hipGraph is being captured only streams that were forked INTO the capture may be waited for: an event recorded on a
+        # stream outside it (the text tower's stream exists process-wide once any model has used it; this step may not) is an external
+        # dependency the captured graph cannot carry -- replays of such a graph came back with corrupted gradients now and then.
+        if not capturing:
+            return True
+        with torch.cuda.stream(s):
+            return torch.cuda.is_current_stream_capturing()
+
+    if OVERLAP_WGRAD and joinable(ops.side_stream()):
         cur.wait_stream(ops.side_stream())
     dev = torch.cuda.current_device()
-    if dev in ops._TEXT and ops._TEXT[dev] != cur:
+    if dev in ops._TEXT and ops._TEXT[dev] != cur and joinable(ops._TEXT[dev]):
         cur.wait_stream(ops._TEXT[dev])
 
 
@@ -199,7 +210,7 @@ def _into(param, value):
     gv = _grad_buf(param)
     if gv is None:
         return value.reshape(param.shape)
-    gv.copy_(value.reshape(param.shape))
+    ops.copy_by_kernel(gv, value.reshape(param.shape))       # (no memcpy nodes in a captured step: see ops.copy_by_kernel)
     return gv
 
 

@@ -63,16 +63,71 @@ def gemm(a, b, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, out
 
 _GEMM_WS = {}
 
+# Scratch buffers are cached per stream (two streams must not share scratch).  A hipGraph capture runs on torch's capture stream, and anything
+# allocated while capturing comes out of THAT graph's private memory pool: a scratch buffer cached under the capture stream's id would be
+# handed to the next capture -- of another shape, of another step object -- long after the pool it lives in was released.  So the thread
+# that captures declares which eager stream its capture stream stands for (the replays run there): scratch is looked up under that
+# stream's id, where the eager warm-up steps allocated it from the ordinary pool, and growing it during a capture is refused.
+_CAPTURE_ALIAS = {}          # capture stream id -> id of the eager stream it stands for
+
+
+class capture_on_behalf_of:
+    """``with capture_on_behalf_of(eager_stream): with torch.cuda.graph(...): ...`` -- see above."""
+
+    def __init__(self, eager_stream):
+        self.eager = eager_stream.cuda_stream
+        self.cap = None
+
+    def note(self):
+        """Call inside the capture context: binds the current (capture) stream to the eager one."""
+        self.cap = torch.cuda.current_stream().cuda_stream
+        if self.cap != self.eager:
+            _CAPTURE_ALIAS[self.cap] = self.eager
+        return self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.cap is not None:
+            _CAPTURE_ALIAS.pop(self.cap, None)
+        return False
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def graph_capture(graph, pool=None):
+    """``torch.cuda.graph`` for code that calls into this library: ``thread_local`` error mode (a loader thread may keep staging, copying and
+    waiting on events while this thread captures) and the cached scratch of the CURRENT stream -- the one the replays will run on."""
+    with capture_on_behalf_of(torch.cuda.current_stream()) as alias:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local", **({"pool": pool} if pool is not None else {})):
+            alias.note()
+            yield graph
+
+
+def _scratch_stream_id():
+    """(id the scratch caches are keyed by, id of the stream the kernels are launched on)"""
+    sid = torch.cuda.current_stream().cuda_stream
+    return _CAPTURE_ALIAS.get(sid, sid), sid
+
 
 def ensure_gemm_workspace(device, mbytes=160):
     """Register (once per device and stream) the scratch the split-K GEMM uses for its fp32 partial slabs."""
-    sid = torch.cuda.current_stream().cuda_stream
-    key = (str(device), sid)
+    key_sid, sid = _scratch_stream_id()
+    key = (str(device), key_sid)
     if key not in _GEMM_WS:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.DemoVLPHipError("GEMM scratch would be allocated inside a hipGraph capture: run the step eagerly once first")
         t = torch.empty(mbytes * 1024 * 1024, device=device, dtype=torch.uint8)
         _GEMM_WS[key] = t
-        call("dvlp_set_workspace_stream", ctypes.c_void_p(sid), p(t), t.numel())
-    return _GEMM_WS[key]
+        call("dvlp_set_workspace_stream", ctypes.c_void_p(key_sid), p(t), t.numel())
+    t = _GEMM_WS[key]
+    if sid != key_sid and _GEMM_WS.get(("alias", str(device), sid)) is not t:
+        call("dvlp_set_workspace_stream", ctypes.c_void_p(sid), p(t), t.numel())     # the capture stream's launches find the same buffer
+        _GEMM_WS[("alias", str(device), sid)] = t
+    return t
 
 
 _SIDE = {}
@@ -166,9 +221,11 @@ _WS = {}
 
 def _workspace(key, nfloat, device):
     """Reusable fp32 scratch, one per (purpose, device, stream): use is ordered by the stream it belongs to."""
-    k = (key, device, torch.cuda.current_stream().cuda_stream)
+    k = (key, device, _scratch_stream_id()[0])
     t = _WS.get(k)
     if t is None or t.numel() < nfloat:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.DemoVLPHipError(f"scratch '{key}' would be (re)allocated inside a hipGraph capture: run the step eagerly at this shape first")
         if t is not None:
             _WS_RETIRED.append(t)       # a captured graph may still point at the smaller buffer: it must never be handed to anyone else
         t = torch.empty(int(nfloat), device=device, dtype=torch.float32)
@@ -456,6 +513,19 @@ def text_embed_bwd(ids, de, vocab):
     dword = torch.zeros((vocab, 768), device=de.device, dtype=torch.float32)
     call("dvlp_text_embed_bwd", dt(de), de.shape[0], p(ids), p(de), p(dword), stream())
     return dword
+
+
+def copy_by_kernel(dst, src):
+    """dst <- src through a kernel launch rather than ``copy_`` (= hipMemcpyAsync for contiguous same-dtype tensors).  Inside a captured
+    step a copy / memset becomes a memcpy / memset NODE, and those were not reliably ordered against the kernels around them when a replay
+    started on an idle device (a hipMemsetAsync in the local-loss backward gave garbage gradients that way): the captured step holds kernel
+    nodes only."""
+    if (dst.dtype in _DT and src.dtype in _DT and not (dst.dtype == src.dtype == torch.bfloat16) and dst.is_contiguous() and src.is_contiguous()
+            and dst.numel() == src.numel() and dst.numel() > 0 and dst.is_cuda):
+        call("dvlp_cast", dt(src), dt(dst), src.numel(), p(src), p(dst), stream())
+    else:
+        dst.copy_(src)
+    return dst
 
 
 def cast(src, dtype, out=None):

@@ -137,7 +137,7 @@ class FusedAdamW:
         for p in self.arena.params:
             g = p.grad
             if g is not None and g.data_ptr() != p._dvlp_grad_view.data_ptr():
-                p._dvlp_grad_view.copy_(g)
+                ops.copy_by_kernel(p._dvlp_grad_view, g)
 
     def prepare(self):
         """Host-side part of a step: everything that inspects autograd state.  After it the flat gradient buffer is final."""
@@ -722,8 +722,9 @@ class GraphedTrainStep:
         self.graphs = []
         for k in range(len(self.cuts) + 1):                 # graphs sharing one memory pool: each consumes what the previous ones saved
             g = torch.cuda.CUDAGraph()
-            # thread_local: a loader thread (data.prefetching) keeps staging, copying and waiting on events while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local", **({"pool": self.graphs[0].pool()} if self.graphs else {})):
+            # ops.graph_capture: thread_local error mode (a loader thread keeps working while this thread captures) and the eager stream's
+            # cached scratch (nothing that is cached may live in this graph's private pool)
+            with ops.graph_capture(g, pool=self.graphs[0].pool() if self.graphs else None):
                 self._piece(k, self.static)
             self.graphs.append(g)
         if not self.collective:

@@ -785,3 +785,31 @@ def test_graph_capture_with_a_prefetching_loader_thread_running():
         losses.append([float(step(d)[0]) for d in it])
         torch.cuda.synchronize()
     assert losses[0] == losses[1], (losses[0], losses[1])
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_replays_with_a_host_synchronisation_between_them(dtype):
+    """A training loop that reads the loss every step (``loss.item()``) synchronises with the device between replays, so every replay
+    starts on an idle GPU.  That is when a hipMemsetAsync captured inside the local-loss backward (a memset NODE) was not ordered against
+    the kernels around it and the video-side gradients came back as garbage: the captured step holds kernel nodes only now, and the
+    synchronised loop must end exactly where the eager loop ends."""
+    from demovlp_amd import functional as Fn
+    F, R, B = 8, 36, 2
+    data = to_dev(*golden_batch(F, R, B))
+    finals = []
+    for graphed in (False, True, True):
+        Fn.SHADOWS.clear()
+        model = build(F, R, dtype)
+        arena = ParamArena(model, bf16_shadow=(dtype == "bfloat16"))
+        opt = FusedAdamW(arena, lr=1e-4)
+        lf = loss_head()
+        stepper = GraphedTrainStep(model, lf, opt, warmup=2) if graphed else None
+        losses = []
+        for _ in range(8):
+            out = stepper(data) if graphed else train_step(model, lf, opt, data)
+            losses.append(out[0].item())                      # host <- device: the next replay finds the GPU idle
+            torch.cuda.synchronize()
+        finals.append((losses, arena.flat_p.clone()))
+    for ls, pf in finals[1:]:
+        assert ls == finals[0][0], (ls, finals[0][0])
+        assert torch.equal(pf, finals[0][1])
