@@ -313,7 +313,7 @@ class ObjectPrologueFn(torch.autograd.Function):
         dcls_row = ops.colsum_grouped(dx, B, 768, N * 768, B, 0, 1, 0).reshape(768)     # sum_b dx[b, 0, :]
         dcls = _into(cls, dcls_row.reshape(1, 1, 768))
         dpos = torch.zeros_like(pos_embed)
-        dpos[0, 0] = dcls_row
+        ops.copy_by_kernel(dpos[0, 0], dcls_row)          # (dpos[0, 0] = dcls_row would be a memcpy node in a captured step)
         dpos = _into(pos_embed, dpos)
         return None, None, dWo, dbo, dWp, dbp, dtemp, dcls, dpos, None
 
@@ -473,7 +473,7 @@ class TextEmbedFn(torch.autograd.Function):
         else:
             dword = ops.text_embed_bwd(ids, de, word.shape[0])
         dpos = torch.zeros_like(pos)
-        dpos[:L] = ops.colsum_grouped(de, B, 768, L * 768, B, 0, L, 768)          # sum over the batch per position
+        ops.colsum_grouped(de, B, 768, L * 768, B, 0, L, 768, out=dpos[:L])       # sum over the batch per position, written in place
         return None, dword, _into(pos, dpos), dg, db, None, None
 
 
