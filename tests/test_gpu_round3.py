@@ -813,3 +813,39 @@ def test_replays_with_a_host_synchronisation_between_them(dtype):
     for ls, pf in finals[1:]:
         assert ls == finals[0][0], (ls, finals[0][0])
         assert torch.equal(pf, finals[0][1])
+
+
+def _graph_dp_bf16_worker(rank, world, port, q, cut):
+    import traceback
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        F, R, B = 8, 36, 2
+        model = build(F, R, "bfloat16")
+        arena = ParamArena(model, bf16_shadow=True)
+        opt = FusedAdamW(arena, lr=1e-4)
+        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0)
+        losses = []
+        for s in range(7):
+            out = stepper(to_dev(*_np_batch(F, R, B, rank, s)))
+            losses.append(float(out[0].item()))                   # host synchronisation every step: each replay starts on an idle device
+            torch.cuda.synchronize()
+        q.put((rank, losses, arena.flat_p.double().cpu().numpy()[::211], float(arena.flat_p.double().sum().item())))
+    except BaseException:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bf16_graphed_step_with_host_sync_is_in_lock_step_and_reproducible():
+    """The data-parallel graph path in bf16 (three graphs, bucketed exchange, optimizer per bucket) with the loss read on the host every
+    step: the two ranks stay bit-equal, every loss is finite, and a second launch of the same job reproduces the first bit for bit."""
+    runs = []
+    for _ in range(2):
+        (_, l0, p0, s0), (_, l1, p1, s1) = _spawn(_graph_dp_bf16_worker, ((8, 4),))
+        assert np.array_equal(p0, p1) and s0 == s1
+        assert np.isfinite(l0).all() and np.isfinite(l1).all() and np.isfinite(p0).all()
+        runs.append((l0, l1, p0, s0))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    assert np.array_equal(runs[0][2], runs[1][2]) and runs[0][3] == runs[1][3]
