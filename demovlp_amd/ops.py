@@ -5,6 +5,7 @@ allocated with the caching allocator (PyTorch is plumbing for device memory and 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 
 import torch
@@ -92,9 +93,6 @@ class capture_on_behalf_of:
         if self.cap is not None:
             _CAPTURE_ALIAS.pop(self.cap, None)
         return False
-
-
-import contextlib
 
 
 @contextlib.contextmanager
