@@ -421,6 +421,9 @@ def main():
                 out["roofline"]["object_transformer_launch_mode"] = obj_mode
                 out["roofline"]["object_transformer_tflops"] = round(B * fpp_obj / obj_s / 1e12, 2)
                 out["roofline"]["object_transformer_frac"] = round(B * fpp_obj / obj_s / 1e12 / peak, 4)
+        if not gemm_n and obj_s is not None:        # (--no-kernel-timing: no roofline object; the object tower's figure stands alone)
+            out["object_transformer"] = {"ms": round(1e3 * obj_s, 3), "launch_mode": obj_mode, "tflops": round(B * fpp_obj / obj_s / 1e12, 2),
+                                         "frac": round(B * fpp_obj / obj_s / 1e12 / peak, 4)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, R)
         print(json.dumps(out), flush=True)

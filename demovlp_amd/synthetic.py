@@ -201,3 +201,78 @@ def fill_state_dict(num_frames: int, object_num: int, time_module=None, qa_label
     if qa_labels:
         schema.update(qa_head_schema(qa_labels))
     return {k: fill_tensor(k, shp) for k, shp in schema.items()}
+
+
+# --------------------------------------------------------------------------------------------------
+# a retrieval set with SIGNAL (golden G11): weights and inputs built so that video i and caption i score above chance
+# --------------------------------------------------------------------------------------------------
+# With the closed-form random weights above the two towers are unrelated, every eval set retrieves at chance (G9: R@1 = 1/256) and a
+# rank swap changes nothing visible.  G11 needs matched pairs to win -- by a margin small enough that R@1 sits near one half, where
+# every rank swap shows.  Everything stays a pure function of seeds:
+#   weights  the closed-form fill, then (a) every residual branch's output projection scaled by RETR_BRANCH (both towers pass their
+#            embedded input through nearly unchanged), (b) object_embedding.weight = [I_768 | 0] (the first 768 feature channels ARE
+#            the embedded token), (c) txt_proj.1.weight = object_model.proj.weight (one shared 256-d head);
+#   captions groups of RETR_GROUP captions share RETR_SHARED of their RETR_WORDS body tokens (hard negatives);
+#   regions  region (f, r) of clip i aims at one body word w of caption i: its feature vector is chosen so that the EMBEDDED token equals
+#            relu(LN_emb(word_emb[id_w] + pos_emb[w])) (the text tower's embedding output, which its six damped layers barely move)
+#            plus Gaussian noise of RETR_NOISE times its rms -- i.e. feature[:768] = target - bias - box term - temporal embedding.
+RETR_BRANCH, RETR_GROUP, RETR_WORDS, RETR_SHARED, RETR_NOISE = 0.05, 8, 12, 9, 2.0
+
+
+def retrieval_state_dict(num_frames: int, object_num: int) -> "dict[str, np.ndarray]":
+    sd = fill_state_dict(num_frames, object_num)
+    for k in list(sd):
+        if k.endswith(("attn.proj.weight", "attn.proj.bias", "mlp.fc2.weight", "mlp.fc2.bias", "attention.out_lin.weight", "attention.out_lin.bias",
+                       "ffn.lin2.weight", "ffn.lin2.bias")):
+            sd[k] = (sd[k] * np.float32(RETR_BRANCH)).astype(np.float32)
+    w = np.zeros((768, FEAT_DIM), np.float32)
+    w[np.arange(768), np.arange(768)] = 1.0
+    sd["object_model.object_embedding.weight"] = w
+    sd["txt_proj.1.weight"] = sd["object_model.proj.weight"].copy()
+    return sd
+
+
+def retrieval_captions(first: int, batch: int, text_len: int = TEXT_LEN):
+    ids = np.zeros((batch, text_len), np.int64)
+    att = np.zeros((batch, text_len), np.int64)
+    for b in range(batch):
+        i = first + b
+        shared = np.random.default_rng(777 + i // RETR_GROUP).integers(1000, VOCAB, RETR_SHARED)
+        own = np.random.default_rng(99991 + i).integers(1000, VOCAB, RETR_WORDS - RETR_SHARED)
+        body = np.concatenate([shared, own])
+        body = body[np.random.default_rng(5 + i).permutation(RETR_WORDS)]
+        n = RETR_WORDS + 2
+        ids[b, 0], ids[b, 1:n - 1], ids[b, n - 1] = 101, body, 102
+        att[b, :n] = 1
+    return ids, att
+
+
+def retrieval_batch(sd, num_frames: int, object_num: int, first: int, batch: int):
+    """(object [B,F,R,2054] f32, mask [B,F,R] f32, input_ids, attention_mask) of pairs first .. first + batch - 1 for the weights ``sd``
+    (= retrieval_state_dict).  float64 inside, rounded once: the same bytes wherever numpy runs."""
+    F_, R = num_frames, object_num
+    ids, att = retrieval_captions(first, batch)
+    we = sd["text_model.embeddings.word_embeddings.weight"].astype(np.float64)
+    pe = sd["text_model.embeddings.position_embeddings.weight"].astype(np.float64)
+    g, bt = sd["text_model.embeddings.LayerNorm.weight"].astype(np.float64), sd["text_model.embeddings.LayerNorm.bias"].astype(np.float64)
+    be = sd["object_model.object_embedding.bias"].astype(np.float64)
+    wp, bp = sd["object_model.pos_embedding.weight"].astype(np.float64), sd["object_model.pos_embedding.bias"].astype(np.float64)
+    te = sd["object_model.temporal_embed"].astype(np.float64)[0]
+    obj = np.zeros((batch, F_, R, FEAT_DIM + BOX_DIM), np.float32)
+    mask = np.ones((batch, F_, R), np.float32)
+    for b in range(batch):
+        i = first + b
+        rng = np.random.default_rng(424242 + i)
+        pos = 1 + rng.integers(0, RETR_WORDS, (F_, R))                       # the body word each region aims at
+        x = we[ids[b, pos]] + pe[pos]
+        x = (x - x.mean(-1, keepdims=True)) / np.sqrt(x.var(-1, keepdims=True) + 1e-12) * g + bt
+        tgt = np.maximum(x, 0.0)
+        tgt = tgt + RETR_NOISE * np.sqrt((tgt ** 2).mean()) * rng.standard_normal(tgt.shape)
+        box = rng.random((F_, R, BOX_DIM))
+        feat = rng.standard_normal((F_, R, FEAT_DIM)) * 0.5                   # channels >= 768 are ignored by the [I | 0] embedding
+        feat[..., :768] = tgt - be - box @ wp.T - bp - te[:F_, None, :]
+        obj[b, ..., :FEAT_DIM], obj[b, ..., FEAT_DIM:] = feat, box
+        npad = i % 4
+        if npad:
+            mask[b, F_ - 1, R - npad:] = 0.0                                   # a few padded regions: the mask path stays exercised
+    return obj, mask, ids, att

@@ -186,6 +186,9 @@ class FusedAdamW:
         if Fn.EARLY_OPT is not None and getattr(Fn.EARLY_OPT, "__self__", None) is self:
             Fn.EARLY_OPT = None
         self._early = None
+        # begin_overlapped() already advanced the DEVICE step counter (adamw_prep_dev) while the host's step_count stays: make the next
+        # _sync_hyper() rewrite the device counter from the host's, or every later step would run its bias correction one step ahead
+        self._hyper_step = -1
 
     def _early_update(self, params):
         a = self.arena
@@ -520,7 +523,10 @@ class GraphedTrainStep:
         self.warmup, self.calls = max(1, warmup), 0
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.bucket = int(bucket_mb * 1024 * 1024 / 4)
+        # (a multiple of the arena's alignment: adamw_range_dev wants 16-byte aligned range starts, and an odd bucket size would make
+        #  every second piece fail in the middle of a step)
+        al = optimizer.arena.ALIGN
+        self.bucket = max(al, int(bucket_mb * 1024 * 1024 / 4) // al * al)
         # always_reduce: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
         self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
         self.graphs, self.static, self.out, self.shape_key = None, None, None, None
@@ -627,6 +633,11 @@ class GraphedTrainStep:
             self.opt._adopt_stray_grads()
         else:
             backward_next(self.model)
+            if not last:
+                # this piece's gradients are exchanged (and consumed by AdamW) right after it: weight gradients still in flight on the
+                # gradient side stream (Fn.OVERLAP_WGRAD) must be joined and stray p.grad copies adopted HERE, not only in the last piece
+                Fn.join_side_stream()
+                self.opt._adopt_stray_grads()
         if last:
             finish_backward(self.model)
             self.opt.prepare()
@@ -681,13 +692,19 @@ class GraphedTrainStep:
         n = len(self.cuts) + 1
         if self.collective and self.opt.arena.flat_g.is_cuda:
             self._begin_updates()
-        for k in range(n):
-            if graphs is not None:
-                graphs[k].replay()
-            else:
-                self._piece(k, data)
-            if self.collective:
-                self._exchange_and_update(self.piece_runs[k])
+        try:
+            for k in range(n):
+                if graphs is not None:
+                    graphs[k].replay()
+                else:
+                    self._piece(k, data)
+                if self.collective:
+                    self._exchange_and_update(self.piece_runs[k])
+        except BaseException:
+            # _begin_updates() advanced the device step counter and earlier pieces may already be updated (their moments too): the
+            # host count did not move, so have the next _sync_hyper() rewrite the device counter from it
+            self.opt._hyper_step = -1
+            raise
         if self.collective:
             if self.opt.arena.flat_g.is_cuda:
                 self._end_updates()
@@ -707,6 +724,14 @@ class GraphedTrainStep:
         of region features at B = 64: ~65 us a step).  Write into them only from the thread / stream that replays the graphs:
         stream order is what keeps batch n + 1 from landing before step n has read batch n."""
         return self.static if self.graphs is not None else None
+
+    def inputs_for(self, data):
+        """The captured input buffers for a batch of ``data``'s shape, or None while that shape has no capture yet (its first ``warmup``
+        calls run eagerly on the caller's own tensors) -- what a loader should ask before ``RegionBatcher.to_device(out=...)``: ``inputs``
+        alone keeps naming the LAST replayed set, whose buffers have another shape when the loader's final batch is smaller.
+        Every captured shape pins its own activation pool (a step's saved activations: ~9 GB at B = 64), up to ``max_shapes`` of them."""
+        have = self._sets.get(self._key(data))
+        return have[1] if have is not None else None
 
     @staticmethod
     def _put(dst, src):
@@ -742,10 +767,11 @@ class GraphedTrainStep:
                 # happen inside a capture are behind it when the capture comes
                 return self._eager(data)
             if len(self._sets) >= self.max_shapes:
-                self._sets.pop(next(iter(self._sets)))        # oldest capture (its memory pool goes with it)
+                self._sets.pop(next(iter(self._sets)))        # least recently used capture (its memory pool goes with it)
             self._capture(data)
             self._sets[key] = (self.graphs, self.static, self.out)
         else:
+            self._sets[key] = self._sets.pop(key)             # most recently used last: eviction takes the front
             self.graphs, self.static, self.out = have
             self.shape_key = key
             for k, v in data["text"].items():

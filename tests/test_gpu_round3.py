@@ -87,6 +87,11 @@ def _graph_dp_worker(rank, world, port, q, cut):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if isinstance(cut, tuple) and cut and cut[-1] == "side-stream":
+            # weight gradients on the gradient side stream: every piece must join it before its ranges are exchanged
+            from demovlp_amd import functional as Fn
+            Fn.OVERLAP_WGRAD = 2
+            cut = cut[:-1]
         F, R, B = 8, 36, 2
         model = build(F, R)
         arena = ParamArena(model)
@@ -106,7 +111,7 @@ def _graph_dp_worker(rank, world, port, q, cut):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cut", [(8, 4), 6, None], ids=["three-graphs-cuts8-4", "two-graphs-cut6", "one-graph"])
+@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), 6, None], ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "two-graphs-cut6", "one-graph"])
 def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     """Two processes on cuda:0, each with its own batch per step, five steps through GraphedTrainStep (two of them replays of the
     captured graphs with the bucketed gradient exchange between / behind them and the fused optimizer applied bucket by bucket on
@@ -114,6 +119,8 @@ def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     1e-5 of max|p| -- to one process that runs both batches, sums the gradients itself and steps with grad_scale 1/2."""
     res = _spawn(_graph_dp_worker, (cut,))
     (_, l0, p0, s0, info), (_, l1, p1, s1, _) = res
+    if isinstance(cut, tuple) and cut[-1] == "side-stream":
+        cut = cut[:-1]
     assert info["captured"] and info["steps"] == NSTEP
     assert info["graph2"] == (cut is not None) and (info["early"] >= 2 if cut is not None else info["early"] == 0)
     assert info["graphs"] == (1 if cut is None else 2 if isinstance(cut, int) else len(cut) + 1)

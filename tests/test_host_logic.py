@@ -335,3 +335,50 @@ def test_two_graph_exchange_plan_covers_the_arena_once():
             assert inside and all(want[k](n) for n in inside) and all(names.index(n) < n_matrix for n in inside)
     last = [n for lo, hi in pieces[3] for n, off in zip(names, offs) if lo <= off < hi]
     assert "object_model.blocks.0.attn.qkv.weight" in last and "txt_proj.1.weight" in last and "text_model.some.bias" in last
+
+
+def test_graphed_step_host_bookkeeping_bucket_alignment_and_lru():
+    """(a) an odd ``bucket_mb`` must not give range starts adamw_range_dev rejects -- the bucket is rounded to the arena's
+    alignment; (b) captured sets are evicted least-recently-USED, not first-captured; (c) ``inputs_for`` names a shape's own buffers and is
+    None while that shape is still in its eager warm-up.  Pure host logic: no kernel is called."""
+    from types import SimpleNamespace
+    from demovlp_amd.trainer import GraphedTrainStep
+    arena = SimpleNamespace(ALIGN=64, total=10 * 64 * 1000)
+    opt = SimpleNamespace(arena=arena)
+    for mb in (0.3, 1.5e-3, 64.0, 1e-9):
+        st = GraphedTrainStep(SimpleNamespace(), None, opt, bucket_mb=mb)
+        assert st.bucket >= 64 and st.bucket % 64 == 0, (mb, st.bucket)
+        pieces = list(st._pieces([(0, arena.total)]))
+        assert pieces[0][0] == 0 and pieces[-1][1] == arena.total and all(lo % 64 == 0 for lo, _ in pieces)
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+    st = GraphedTrainStep(SimpleNamespace(), None, opt)
+    st.max_shapes, st.warmup = 2, 1
+    captured, replays = [], []
+
+    def batch(n):
+        return {"text": {"input_ids": torch.zeros(n, 4, dtype=torch.long), "attention_mask": torch.ones(n, 4)}, "object": torch.zeros(n, 2, 3, 8),
+                "object_mask": torch.ones(n, 2)}
+    st._eager = lambda d: ("eager", d["object"].shape[0])
+
+    def fake_capture(d):
+        n = d["object"].shape[0]
+        captured.append(n)
+        st.graphs = [SimpleNamespace(replay=lambda n=n: replays.append(n))]
+        st.static = {"text": {k: v.clone() for k, v in d["text"].items()}, "object": d["object"].clone(), "object_mask": d["object_mask"].clone()}
+        st.out = (torch.zeros(()),)
+        st.shape_key = st._key(d)
+    st._capture = fake_capture
+    st.opt = SimpleNamespace(_sync_hyper=lambda s: None, replayed=lambda: None, arena=arena)
+    assert st.inputs_for(batch(4)) is None
+    assert st(batch(4))[0] == "eager" and st.inputs_for(batch(4)) is None          # warm-up call: no capture yet
+    st(batch(4))                                                                    # captured + replayed
+    assert captured == [4] and st.inputs_for(batch(4))["object"].shape[0] == 4
+    st(batch(3)); st(batch(3))                                                      # second shape
+    assert captured == [4, 3] and st.inputs_for(batch(3))["object"].shape[0] == 3 and st.inputs_for(batch(4))["object"].shape[0] == 4
+    st(batch(4))                                                                    # touch shape 4: shape 3 is now the least recently used
+    st(batch(2)); st(batch(2))                                                      # third shape evicts ... shape 3, not the main shape 4
+    assert captured == [4, 3, 2]
+    assert st.inputs_for(batch(3)) is None and st.inputs_for(batch(4)) is not None and st.inputs_for(batch(2)) is not None
+    n_before = len(captured)
+    st(batch(4))
+    assert len(captured) == n_before                                               # still captured: replayed, not re-captured

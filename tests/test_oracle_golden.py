@@ -190,10 +190,25 @@ def test_eval_pipeline_vs_reference():
     assert rel_err(gs, g["global_sims"]) < 1e-4 and rel_err(ls, g["local_sims"][:S, :S]) < 1e-4
     o2t = gs[:S, :S] + ls                           # [text, video] + [video, text]: the reference's own orientation mix
     assert rel_err(o2t, g["o2t_sims"][:S, :S]) < 1e-4
+    # off-block entries of the local grid: 8 videos x 8 captions drawn from the other 208 of each (the full 256 x 256 grid is the GPU test's job:
+    # 65 536 per-pair attentions take minutes on the host)
+    rng = np.random.default_rng(9)
+    vi, ti = np.sort(rng.choice(np.arange(S, 256), 8, replace=False)), np.sort(rng.choice(np.arange(S, 256), 8, replace=False))
+    with torch.no_grad():
+        off = orc.xattn_scores_batched(cat["lo"][vi], cat["lt"][ti], cat["om"][vi].float(), cat["tm"][ti]).numpy()
+    assert rel_err(off, g["local_sims"][np.ix_(vi, ti)]) < 1e-4
+    # the metrics over ALL 256 pairs from the COMPUTED global similarities (+ the computed local block / entries; the golden local grid elsewhere)
+    local = g["local_sims"].copy()
+    local[:S, :S] = ls
+    local[np.ix_(vi, ti)] = off
+    full = gs + local
+    assert rel_err(full, g["o2t_sims"]) < 1e-4
     keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
     for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
         r = fn(g["o2t_sims"])
         assert np.allclose([r[k] for k in keys], g[name], rtol=1e-9, atol=1e-9), name
+        r2 = fn(full)                                # computed sims: R@K may differ by the pairs a 1e-5 perturbation re-orders
+        assert abs(r2["R1"] - r["R1"]) <= 100.0 * 2 / 256 and abs(r2["MedR"] - r["MedR"]) <= 2 and abs(r2["MeanR"] - r["MeanR"]) <= 1.0, name
 
 
 def test_philox_known_answer_vectors():
