@@ -862,6 +862,11 @@ __device__ __attribute__((noinline)) void p8_store_ragged(const Epi& e, bf16* __
 #ifdef DVLP_STAMP
 __device__ unsigned long long* g_p8_stamp = nullptr;
 extern "C" int dvlp_p8_stamp_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_p8_stamp), &p, sizeof p) == hipSuccess ? DVLP_OK : DVLP_ERR_LAUNCH; }
+// timing experiment (P8_ALIAS=1 python tools/p8_timeline.py): every workgroup LOADS the operands of tile (0, 0) (outputs still go to its own
+// tile), i.e. the whole chip streams the same two panels out of L2 -- does a full-chip K loop run at the speed it has on 60 CUs once the
+// memory system is taken out?  Round 4: no (21.5 vs 21.3 us stamped; 17.0 on 60 CUs): the full-chip K loop is clock-bound, not fill-bound.
+__device__ int g_p8_alias = 0;
+extern "C" int dvlp_p8_alias(int on) { return hipMemcpyToSymbol(HIP_SYMBOL(g_p8_alias), &on, sizeof on) == hipSuccess ? DVLP_OK : DVLP_ERR_LAUNCH; }
 #define P8_STAMP(i) do { if (st) st[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // per-phase shader-clock stamps inside the K loop (issued where they are taken, consumed at the end of the phase so that no extra wait lands
 // between the fragment reads and the barrier): where a phase spends its time -- load segment, first barrier, MFMA cluster, second barrier
@@ -938,6 +943,9 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
             sp[2][j] = cur_of(src_ptr(FB{}, B, ldb, n0_ + 128, N, j), B);
         }
     };
+#ifdef DVLP_STAMP
+    if (g_p8_alias) set_ptrs(0, 0); else
+#endif
     set_ptrs(m0, n0);          // PERS, follow-on tile: units 0..5 were staged by the previous tile; the cursors are rebuilt and advanced
                                // below (cheaper than keeping them alive across the epilogue)
     const int64_t kstepA = A_R ? H_BK * lda : H_BK, kstepB = B_R ? H_BK * ldb : H_BK;

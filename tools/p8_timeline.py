@@ -31,6 +31,10 @@ dev = "cuda"
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)  # noqa: E731
 g = torch.Generator(device=dev).manual_seed(0)
 M0 = 18496
+if os.environ.get("P8_ALIAS"):              # every workgroup loads tile (0, 0)'s operands: the memory system taken out of the K loop
+    lib.dvlp_p8_alias.argtypes = [ctypes.c_int]
+    lib.dvlp_p8_alias(1)
+    print("# P8_ALIAS=1: all workgroups load the operands of tile (0, 0)")
 lib.dvlp_gemm_p8_mode(2)                    # also for grids the dispatch would give to the 128-row kernel
 lib.dvlp_gemm_p8_persistent(0)              # the stamps live in the one-tile-per-workgroup kernel
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
