@@ -216,7 +216,7 @@ def fill_state_dict(num_frames: int, object_num: int, time_module=None, qa_label
 #   regions  region (f, r) of clip i aims at one body word w of caption i: its feature vector is chosen so that the EMBEDDED token equals
 #            relu(LN_emb(word_emb[id_w] + pos_emb[w])) (the text tower's embedding output, which its six damped layers barely move)
 #            plus Gaussian noise of RETR_NOISE times its rms -- i.e. feature[:768] = target - bias - box term - temporal embedding.
-RETR_BRANCH, RETR_GROUP, RETR_WORDS, RETR_SHARED, RETR_NOISE = 0.05, 8, 12, 9, 2.0
+RETR_BRANCH, RETR_GROUP, RETR_WORDS, RETR_SHARED, RETR_NOISE = 0.05, 8, 12, 11, 6.0
 
 
 def retrieval_state_dict(num_frames: int, object_num: int) -> "dict[str, np.ndarray]":

@@ -439,6 +439,59 @@ def golden_eval(ref_model, ref_loss, ref_data, scratch):
     np.savez_compressed(os.path.join(HERE, "g9_eval.npz"), **out)
 
 
+def golden_retrieval(ref_model, ref_loss):
+    """G11: the reference's retrieval evaluation (the same driver as G9) on a set WITH retrieval signal -- demovlp_amd/synthetic.py:
+    retrieval_state_dict / retrieval_batch: damped residual branches, one shared 256-d head, region features that land on the caption's
+    word embeddings plus noise, captions in groups of 8 that differ by one word -- so that R@1 sits far from both chance (1/256) and 100 %
+    and every rank swap between near neighbours moves a metric.  256 pairs, F = 8, R = 30, batches of 32."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("refmetric", "/root/reference/model/metric.py")
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    F, R, BS, NB = 8, 30, 32, 8
+    m = build_reference_model(ref_model, F, R)
+    sd = syn.retrieval_state_dict(F, R)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            v.copy_(torch.from_numpy(sd[k]))
+    m.eval()
+    loss_fn = ref_loss.GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+    acc = {k: [] for k in ("gt", "go", "lt", "lo", "len", "om", "tm")}
+    val = []
+    with torch.no_grad():
+        for b in range(NB):
+            obj, mask, ids, att = syn.retrieval_batch(sd, F, R, b * BS, BS)
+            data = {"text": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(att)}, "object": torch.from_numpy(obj),
+                    "object_mask": torch.from_numpy(mask)}
+            text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+            text_mask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+            o = m(data, return_embeds=True)
+            for k, v in zip(acc, (o["global_text_embeddings"], o["global_object_embeddings"], o["local_text_embeddings"],
+                                  o["local_object_embeddings"], text_length, o["object_mask"], text_mask)):
+                acc[k].append(v)
+            loss, gl, ll = loss_fn(ref_model.sim_matrix(o["global_text_embeddings"], o["global_object_embeddings"]), o["local_object_embeddings"],
+                                   o["local_text_embeddings"], o["object_mask"], text_length, text_mask)
+            val.append([loss.item(), gl.item(), ll.item()])
+        cat = {k: torch.cat(v) for k, v in acc.items()}
+        gs = ref_model.sim_matrix(cat["gt"], cat["go"]).detach().cpu().numpy()
+        ls = loss_fn.local_loss.get_sim_by_segment(cat["lo"], cat["lt"], cat["om"], cat["len"], cat["tm"], device="cpu")
+    o2t = gs + ls
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    out = dict(F=F, R=R, batch=BS, batches=NB, val_losses=np.array(val, np.float64), global_sims=gs, local_sims=ls, o2t_sims=o2t)
+    for name, fn in (("t2v", rm.t2v_metrics), ("v2t", rm.v2t_metrics)):
+        r = fn(o2t)
+        out[name] = np.array([r[k] for k in keys], np.float64)
+        print("g11", name, {k: round(float(r[k]), 3) for k in keys})
+    # how close the decisions are: per query, the gap between the best and the second-best score (a rank-1 swap needs a perturbation of that size)
+    srt = np.sort(o2t, axis=1)
+    out["top_gap_t2v"] = (srt[:, -1] - srt[:, -2]).astype(np.float64)
+    srt = np.sort(o2t, axis=0)
+    out["top_gap_v2t"] = (srt[-1] - srt[-2]).astype(np.float64)
+    print("g11 top-1 gaps: t2v median %.2e min %.2e   v2t median %.2e min %.2e" % (np.median(out["top_gap_t2v"]), out["top_gap_t2v"].min(),
+                                                                                     np.median(out["top_gap_v2t"]), out["top_gap_v2t"].min()))
+    np.savez_compressed(os.path.join(HERE, "g11_retrieval.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -455,6 +508,8 @@ def main():
             golden_eval(ref_model, ref_loss, ref_data, scratch)
         if "g10" in only:
             golden_qa(ref_model, ref_loss, ref_data, scratch)
+        if "g11" in only:
+            golden_retrieval(ref_model, ref_loss)
         return
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
@@ -467,6 +522,7 @@ def main():
     golden_loss_curve(ref_model, ref_loss, ref_data, scratch)
     golden_eval(ref_model, ref_loss, ref_data, scratch)
     golden_qa(ref_model, ref_loss, ref_data, scratch)
+    golden_retrieval(ref_model, ref_loss)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,130 @@
+"""Round-4 parity coverage on a real MI355X:
+
+* retrieval evaluation where retrieval WORKS (golden G11: t2v R@1 91 %, v2t R@1 23 %, MedR 8 on 256 pairs; G9 sits at chance): the fp32
+  path must reproduce every query's rank -- hence R@1/5/10/50, MedR, MeanR -- except for queries whose decision the reference itself
+  makes by less than the 1e-4 similarity bar; the bf16 path within a stated number of rank changes
+  (trainer/trainer_dist.py:358-399, model/metric.py:10-122);
+* bf16 training fidelity at the benchmark size: 20 graph-replayed optimisation steps at B = 64, F = 8, R = 36 against the fp32 HIP
+  path on the same batches, at the config's lr 1e-5 and at the 2e-4 the reference's schedule quirk switches to
+  (trainer/trainer_dist.py:144-171): per-step loss deviation, direction and size of the parameter update.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demovlp_amd import synthetic as syn  # noqa: E402
+from demovlp_amd.loss import GlobalLocalLoss  # noqa: E402
+from demovlp_amd.model import ObjectRelation  # noqa: E402
+from demovlp_amd.trainer import evaluate  # noqa: E402
+from helpers import load_golden, rel_err  # noqa: E402
+
+DEV = "cuda"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _retrieval_model(F, R, sd, dtype):
+    m = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
+                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.set_text_dropout(0.0)
+    return m.to(DEV)
+
+
+def _retrieval_batches(sd, F, R, BS, NB):
+    for b in range(NB):
+        obj, mask, ids, att = syn.retrieval_batch(sd, F, R, b * BS, BS)
+        yield {"text": {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(att).to(DEV)},
+               "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
+
+
+def _match_ranks(sims, axis):
+    """Rank (0 = best) of the matching item for every query: t2v queries are rows (axis 1 runs over videos), v2t queries columns."""
+    s = sims if axis == 1 else sims.T
+    d = np.diag(s)
+    return (s > d[:, None]).sum(1)
+
+
+def _ambiguous(sims, axis, tol):
+    """Queries whose match competes with another item inside +-tol: the only ones whose rank a deviation below tol / 2 can change."""
+    s = sims if axis == 1 else sims.T
+    d = np.diag(s)
+    close = np.abs(s - d[:, None]) < tol
+    np.fill_diagonal(close, False)
+    return close.any(1)
+
+
+KEYS = ("R1", "R5", "R10", "R50", "MedR", "MeanR")
+
+
+def test_fp32_evaluate_reproduces_every_rank_of_the_retrieval_set_with_signal():
+    g = load_golden("g11_retrieval.npz")
+    F, R, BS, NB = int(g["F"]), int(g["R"]), int(g["batch"]), int(g["batches"])
+    n = BS * NB
+    sd = syn.retrieval_state_dict(F, R)
+    model = _retrieval_model(F, R, sd, "float32")
+    res = evaluate(model, GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal"), _retrieval_batches(sd, F, R, BS, NB))
+    assert abs(res["val_loss"] - g["val_losses"][:, 0].mean()) < 1e-4 * g["val_losses"][0, 0]
+    assert rel_err(res["global_sims"], g["global_sims"]) < 1e-4 and rel_err(res["local_sims"], g["local_sims"]) < 1e-4
+    dev = np.abs(res["o2t_sims"] - g["o2t_sims"]).max()
+    assert dev < 1e-4 * max(1.0, np.abs(g["o2t_sims"]).max())
+    for name, axis in (("t2v", 1), ("v2t", 0)):
+        want, got = _match_ranks(g["o2t_sims"], axis), _match_ranks(res["o2t_sims"], axis)
+        amb = _ambiguous(g["o2t_sims"], axis, 2.0 * dev)
+        changed = want != got
+        print("\n%s: max |sim dev| %.2e; %d of %d queries decided by less than twice that; ranks changed: %d" % (name, dev, amb.sum(), n, changed.sum()))
+        assert not (changed & ~amb).any()                        # every clearly decided query keeps its exact rank
+        assert np.abs(want - got).max() <= max(1, amb.sum())     # ... and an ambiguous one moves by the few neighbours it is tied with
+        m = res["nested_val_metrics"][name + "_metrics"]
+        ref = dict(zip(KEYS, g[name][:6]))
+        if not changed.any():
+            assert all(abs(m[k] - ref[k]) < 1e-9 for k in KEYS), (name, m, ref)          # R@1/5/10/50, MedR, MeanR: exact
+        else:
+            assert all(abs(m[k] - ref[k]) <= 100.0 * changed.sum() / n + 1e-9 for k in KEYS[:4]) and abs(m["MeanR"] - ref["MeanR"]) <= np.abs(want - got).sum() / n + 1e-9
+    assert g["t2v"][0] > 50.0 and 10.0 < g["v2t"][0] < 60.0      # the set is neither at chance nor saturated
+
+
+# bf16 bounds: measured on MI355X (printed by the test), then doubled
+BF16_G11_SIM_TOL = 2e-2           # observed 7.6e-3
+BF16_G11_R_AT_K = 4.0            # percentage points on R@1/5/10/50 (observed: 1.6, with 104 of 256 v2t ranks moved by up to 6 places)
+BF16_G11_MEANR = 1.0             # observed 0.01
+
+
+def test_bf16_evaluate_on_the_retrieval_set_with_signal_stays_within_stated_rank_changes():
+    g = load_golden("g11_retrieval.npz")
+    F, R, BS, NB = int(g["F"]), int(g["R"]), int(g["batch"]), int(g["batches"])
+    n = BS * NB
+    sd = syn.retrieval_state_dict(F, R)
+    model = _retrieval_model(F, R, sd, "bfloat16")
+    res = evaluate(model, GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal"), _retrieval_batches(sd, F, R, BS, NB))
+    d = np.abs(res["o2t_sims"] - g["o2t_sims"]).max() / np.abs(g["o2t_sims"]).max()
+    assert d < BF16_G11_SIM_TOL, d
+    for name, axis in (("t2v", 1), ("v2t", 0)):
+        want, got = _match_ranks(g["o2t_sims"], axis), _match_ranks(res["o2t_sims"], axis)
+        m = res["nested_val_metrics"][name + "_metrics"]
+        ref = dict(zip(KEYS, g[name][:6]))
+        print("\n%s bf16: o2t rel dev %.2e; %d of %d ranks changed (max by %d); R@1/5/10/50 %s vs %s; MedR %s vs %s; MeanR %.2f vs %.2f"
+              % (name, d, (want != got).sum(), n, np.abs(want - got).max(), [round(m[k], 2) for k in KEYS[:4]], np.round(g[name][:4], 2), m["MedR"], ref["MedR"],
+                 m["MeanR"], ref["MeanR"]))
+        assert all(abs(m[k] - ref[k]) <= BF16_G11_R_AT_K for k in KEYS[:4]), (name, m, ref)
+        assert abs(m["MedR"] - ref["MedR"]) <= 2.0 and abs(m["MeanR"] - ref["MeanR"]) <= BF16_G11_MEANR
+        assert m["R1"] > 0.5 * ref["R1"]                                                  # the signal survives bf16
+
+
+# measured on MI355X (profiles/r4_bf16_fidelity.txt), bounds = 2-2.5x the observation:
+#   lr 1e-5, 20 steps: max |loss16 - loss32| 3.4e-3 (1.9e-4 of the loss), |p16 - p32| = 0.115 |p32 - p0|, cos(update16, update32) 0.9934
+#   lr 2e-4, 10 steps: 4.6e-2 at the step-3 spike (2.4e-3 of the loss)
+@pytest.mark.parametrize("lr,steps,rel_tol,drift_tol,cos_min", [(1e-5, 20, 5e-4, 0.25, 0.98), (2e-4, 10, 6e-3, 0.6, 0.90)], ids=["lr1e-5", "lr2e-4"])
+def test_bf16_trains_like_fp32_at_the_benchmark_size(lr, steps, rel_tol, drift_tol, cos_min):
+    from bf16_fidelity import fidelity
+    r = fidelity(lr, steps=steps, B=64, verbose=False)
+    print("\nlr %g, %d steps at B = 64: max |loss16 - loss32| %.2e (%.2e of the loss); |p16 - p32| / |p32 - p0| = %.3f; cos(update16, update32) = %.4f; "
+          "loss %.4f -> %.4f (fp32) / %.4f -> %.4f (bf16)" % (lr, steps, r["max_dev"], r["max_rel"], r["drift"], r["cos"], r["l32"][0, 0], r["l32"][-1, 0],
+                                                            r["l16"][0, 0], r["l16"][-1, 0]))
+    assert r["max_rel"] < rel_tol and r["drift"] < drift_tol and r["cos"] > cos_min
+    assert np.isfinite(r["l16"]).all() and r["l16"][-1, 0] < r["l16"][0, 0]                # it descends, as the fp32 run does
+    assert abs((r["l16"][0, 0] - r["l16"][-1, 0]) - (r["l32"][0, 0] - r["l32"][-1, 0])) < 0.1 * abs(r["l32"][0, 0] - r["l32"][-1, 0]) + 2 * r["max_dev"]

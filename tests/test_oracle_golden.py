@@ -240,3 +240,39 @@ def test_qa_head_vs_reference():
     loss.backward()
     for k, n in zip(g["grad_names"], g["grad_norms"]):
         assert abs(float(p[k].grad.double().norm()) - n) <= 1e-3 * max(n, 1e-6), k
+
+
+def test_oracle_vs_reference_on_the_retrieval_set_with_signal():
+    """G11 (make_golden.py:golden_retrieval): the reference's evaluation on 256 pairs built to retrieve far from chance (t2v R@1 91 %, v2t
+    R@1 23 %, MedR 8).  Here: the generator is deterministic (same bytes as the golden run saw), the oracle reproduces the first two
+    batches' validation losses, the global similarities of those 64 pairs and a 32 x 32 block of the local grid; the stored metrics follow
+    from the stored similarity matrix.  The full 256-pair comparison runs on the device (tests/test_gpu_round4.py)."""
+    from demovlp_amd import metric
+    g = load_golden("g11_retrieval.npz")
+    F, R, BS = int(g["F"]), int(g["R"]), int(g["batch"])
+    assert g["t2v"][0] > 50.0 and 10.0 < g["v2t"][0] < 60.0 and g["v2t"][4] > 2          # far from chance AND from saturation
+    torch.set_num_threads(8)
+    sd = syn.retrieval_state_dict(F, R)
+    p = orc.params_from_numpy(sd)
+    acc = {k: [] for k in ("gt", "go", "lt", "lo", "om", "tm")}
+    with torch.no_grad():
+        for b in range(2):
+            obj, mask, ids, att = syn.retrieval_batch(sd, F, R, b * BS, BS)
+            out = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask))
+            tm = (torch.from_numpy(att)[:, 1:].float() - 1.0) * 100.0
+            for k, v in zip(acc, (out["global_text_embeddings"], out["global_object_embeddings"], out["local_text_embeddings"],
+                                  out["local_object_embeddings"], out["object_mask"], tm)):
+                acc[k].append(v)
+            loss, gl, ll, _, _ = orc.global_local_loss(out, tm)
+            assert np.abs(np.array([loss.item(), gl.item(), ll.item()]) - g["val_losses"][b]).max() < 1e-4 * max(1.0, g["val_losses"][b][0])
+        cat = {k: torch.cat(v) for k, v in acc.items()}
+        n = 2 * BS
+        gs = orc.sim_matrix(cat["gt"], cat["go"]).numpy()
+        S = 32
+        ls = orc.xattn_scores_batched(cat["lo"][:S], cat["lt"][:S], cat["om"][:S].float(), cat["tm"][:S]).numpy()
+    assert rel_err(gs, g["global_sims"][:n, :n]) < 1e-4 and rel_err(ls, g["local_sims"][:S, :S]) < 1e-4
+    assert ls.diagonal().mean() > np.delete(ls, np.arange(S) * (S + 1)).mean() + 0.02           # matched pairs do score higher
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
+        r = fn(g["o2t_sims"])
+        assert np.allclose([r[k] for k in keys], g[name], rtol=1e-9, atol=1e-9), name
