@@ -80,23 +80,30 @@ def test_fp32_forward_backward_vs_reference_golden(tag):
             assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6), name
 
 
+# bf16 bounds at B = 2: measured on MI355X (the test prints them), then doubled
+BF16_B2 = dict(emb=2.0e-2, sim=3.0e-3, loss=2.5e-3, gnorm=7.0e-2)      # observed 1.03e-2 / 1.31e-3 / 1.23e-3 / 3.4e-2 (median gradient-norm deviation 1.75e-2)
+
+
 def test_bf16_forward_backward_close_to_reference():
-    """bf16 MFMA path: embeddings within 3e-2 of max|ref|, losses within 2e-2 relative (stated tolerance; the 1e-4 bar
-    applies to the fp32 path)."""
+    """bf16 MFMA path against the reference's fp32 golden at B = 2: embeddings / sim_matrix relative to max|ref|, the three losses
+    relative to the total, and the norm of every gradient tensor (n > 1e-3) relative to its own -- bounds = twice the measured
+    deviation (the 1e-4 bar applies to the fp32 path)."""
     g = load_golden("g2_model_F8_R36_B2.npz")
     model = build(8, 36, "bfloat16")
     out, gsim, xs, loss, gl, ll = run(model, batch(8, 36, 2))
-    for k in ("global_text_embeddings", "local_text_embeddings", "global_object_embeddings", "local_object_embeddings"):
-        assert rel_err(out[k].detach().float().cpu().numpy(), g[k]) < 3e-2, k
-    assert rel_err(gsim.detach().cpu().numpy(), g["sim_matrix"]) < 3e-2
+    emb = max(rel_err(out[k].detach().float().cpu().numpy(), g[k]) for k in
+              ("global_text_embeddings", "local_text_embeddings", "global_object_embeddings", "local_object_embeddings"))
+    sim = rel_err(gsim.detach().cpu().numpy(), g["sim_matrix"])
     got = np.array([loss.item(), gl.item(), ll.item()])
-    assert np.abs(got - g["losses"]).max() < 3e-2 * g["losses"][0], (got, g["losses"])
+    dl = np.abs(got - g["losses"]).max() / g["losses"][0]
     loss.backward()
     named = dict(model.named_parameters())
     norms = dict(zip(g["grad_names"], g["grad_norms"]))
-    bad = [(k, float(named[k].grad.double().norm()), n) for k, n in norms.items()
-           if n > 1e-3 and abs(float(named[k].grad.double().norm()) - n) / n > 0.15]
-    assert not bad, bad[:5]
+    devs = sorted(((abs(float(named[k].grad.double().norm()) - n) / n, k) for k, n in norms.items() if n > 1e-3), reverse=True)
+    print("\nbf16 vs reference at B = 2: embeddings %.2e, sim_matrix %.2e, losses %.2e of the total, gradient norms: worst %.2e (%s), median %.2e"
+          % (emb, sim, dl, devs[0][0], devs[0][1], devs[len(devs) // 2][0]))
+    assert emb < BF16_B2["emb"] and sim < BF16_B2["sim"] and dl < BF16_B2["loss"], (emb, sim, dl)
+    assert devs[0][0] < BF16_B2["gnorm"], devs[:5]
 
 
 @pytest.mark.parametrize("overlap", [0, 1, 2], ids=["one-stream", "bgrad-side-stream", "wgrad-side-stream"])
