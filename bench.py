@@ -193,8 +193,8 @@ def main():
                     help="side-stream gradient work: 0 off (default: per-kernel timings stay well defined), 1 bias-gradient reductions, "
                          "2 also weight-gradient GEMMs (+6%% pairs/s, but concurrent GEMMs stretch each other)")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
-                    help="developer A/B switch: call the C-ABI setter NAME (e.g. dvlp_xattn_gram=0) before the first step; repeatable")
-    ap.add_argument("--p8", type=int, default=-1, help="override dvlp_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
+                    help="developer A/B switch: call the C-ABI setter NAME (e.g. dvlp_dev_xattn_gram=0) before the first step; repeatable")
+    ap.add_argument("--p8", type=int, default=-1, help="override dvlp_dev_gemm_p8_mode (0 never / 1 heuristic / 2 always use the 256x256 GEMM kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP-event timing of the GEMMs")
     ap.add_argument("--no-object-tower", action="store_true", help="skip the object-transformer-only fwd+bwd timing")
     ap.add_argument("--parallel-towers", type=int, default=1, help="1 (default): text tower on its own HIP stream, concurrent with the object tower; 0: one stream")
@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
                          "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1, graph mode: dtype of the gradient buckets on the links (bf16 = half the bytes; moments and master weights stay fp32)")
     ap.add_argument("--gather-negatives", action="store_true",
                     help="cross-GPU negatives: all-gather the embeddings for the contrastive losses (opt-in; the reference trains "
                          "with per-rank negatives, trainer/trainer_dist.py:148-165)")
@@ -249,7 +251,7 @@ def main():
     import demovlp_amd.functional as Fn
     Fn.OVERLAP_WGRAD = int(a.overlap_wgrad)
     if a.p8 >= 0:
-        ops.call("dvlp_gemm_p8_mode", a.p8)
+        ops.call("dvlp_dev_gemm_p8_mode", a.p8)
     for kv in a.knob:
         name, val = kv.split("=")
         ops.call(name, int(val))
@@ -263,7 +265,7 @@ def main():
     model.parallel_towers = bool(a.parallel_towers)
     reducer, stepper = None, None
     if use_graph:
-        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist)
+        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist, grad_dtype="bfloat16" if a.grad_dtype == "bf16" else "float32")
     elif world > 1 or force_dist:
         reducer = GradReducer(arena, bucket_mb=64.0, always_reduce=force_dist)
 
@@ -348,6 +350,17 @@ def main():
             dist.all_reduce(arena.flat_g)
         sync()
         allreduce_ms = round(1e3 * (time.perf_counter() - t1) / 3, 3)
+    exchange = None
+    if (world > 1 or force_dist) and use_graph and getattr(stepper, "collective", False):
+        # per-piece exchange times: three more steps with HIP events around every piece's collectives on the communication stream (outside the
+        # timed region: the events make the host wait for each piece's handles)
+        stepper.time_exchange = True
+        for _ in range(3):
+            stepper(data)
+        xt = stepper.exchange_times()
+        stepper.time_exchange = False
+        npieces = len(stepper.piece_runs)
+        exchange = [{"piece": k, "mb": round(xt[k][1] / 2 ** 20, 1), "ms": round(sum(t for t, _ in xt[k::npieces]) / max(1, len(xt[k::npieces])), 3)} for k in range(npieces)]
     obj_s, obj_mode = None, None
     if not a.no_object_tower:
         obj_s, obj_mode = time_object_tower(model, data, max(3, min(a.steps, 10)), sync, graph=use_graph)
@@ -379,6 +392,9 @@ def main():
             out["per_rank_pairs_per_s"] = per_rank
             out["grad_allreduce_ms_standalone"] = allreduce_ms
             out["grad_allreduce_bytes"] = int(arena.flat_g.numel() * 4)
+            if exchange is not None:
+                out["grad_exchange_pieces"] = exchange          # time each piece's collectives occupy the communication stream (all but the last run beside the next graph)
+                out["grad_exchange_dtype"] = a.grad_dtype
             if use_graph and getattr(stepper, "graph2", None) is not None:
                 sizes = [sum(hi - lo for lo, hi in runs) * 4 >> 20 for runs in stepper.piece_runs]
                 out["grad_exchange"] = ("backward captured as %d graphs cut at object blocks %s: the gradients a piece finishes (%s MB: text tower + top blocks first, "

@@ -50,11 +50,15 @@ struct AttnArgs {
     // per (b, frame) written by that frame's 12 head waves + one row per b for the CLS token's rows; summed by the deferred-reduction queue
     float* csum;
 };
-static thread_local const uint8_t *t_keep = nullptr, *t_keepT = nullptr;
-static thread_local float t_kscale = 1.f;
-extern "C" int dvlp_attention_dropout_next(const void* keep, const void* keepT, float scale) {
-    t_keep = (const uint8_t*)keep; t_keepT = (const uint8_t*)keepT; t_kscale = scale; return DVLP_OK;
-}
+// Optional extras of dvlp_attention_fwd_ex / dvlp_attention_bwd_ex (include/demovlp_hip.h: dvlp_attn_ext), handed to the call that consumes
+// them.  (Rounds 2-3 armed these through thread-local "next call" setters: an exception between the two calls left a stale device
+// pointer armed for an unrelated launch.)
+struct dvlp_attn_ext {
+    const void* keep; const void* keepT; float keep_scale;      // mode 1: dropout of the attention probabilities (dvlp_dropout_attn_mask)
+    float* colsum;                                              // backward, mode 0: column sums of dq | dk | dv wanted here (or NULL)
+    int colsum_fused;                                           // out: the backward queued them (else the caller sums the columns)
+    int folded;                                                 // out: the forward folded the CLS query and filled cls_stats
+};
 // four consecutive keep bytes as multipliers
 __device__ __forceinline__ void keep4(const uint8_t* p, float scale, float (&m)[4]) {
     const uint32_t kb = *(const uint32_t*)p;
@@ -63,8 +67,8 @@ __device__ __forceinline__ void keep4(const uint8_t* p, float scale, float (&m)[
 }
 static int g_attn_abl = 0;
 static int g_attn_merged = 1;      // space-mode bf16 backward: 1 = one-pass form, 0 = the three-launch form (A/B, tests)
-extern "C" int dvlp_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
-extern "C" int dvlp_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
+extern "C" int dvlp_dev_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
+extern "C" int dvlp_dev_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
@@ -1311,33 +1315,25 @@ static int attn_check(const AttnArgs& a) {
 }
 
 float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out);      // norm.hip: deferred-reduction queue
-static thread_local float* t_attn_csum_next = nullptr;
-static thread_local int t_attn_csum_fused = 0;
-// the NEXT dvlp_attention_bwd (mode 0) of this host thread also queues the column sums of dq | dk | dv ([3*H*64] fp32: the packed qkv bias
-// gradient) into `dst` when it can (bf16 one-pass form with forward statistics, deferred reductions enabled); dvlp_attention_bwd_colsum_fused()
-// says whether the last call did -- if not, the caller runs its own column-sum pass
-extern "C" int dvlp_attention_bwd_colsum_next(float* dst) { t_attn_csum_next = dst; return DVLP_OK; }
-extern "C" int dvlp_attention_bwd_colsum_fused() { return t_attn_csum_fused; }
+// (dvlp_attn_ext::colsum: the backward (mode 0) also queues the column sums of dq | dk | dv ([3*H*64] fp32: the packed qkv bias gradient)
+//  when it can -- bf16 one-pass form with forward statistics, deferred reductions enabled -- and says so in colsum_fused)
 static int g_attn_fold = 1;        // space-mode bf16: 1 = CLS query folded into the frame waves when the caller passes workspaces, 0 = separate launches (A/B, tests)
-extern "C" int dvlp_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
-static thread_local int t_attn_fwd_folded = 0;
-// 1 if the last dvlp_attention_fwd of this host thread folded the CLS query and filled `cls_stats` (only then may they be handed to the backward)
-extern "C" int dvlp_attention_fwd_folded() { return t_attn_fwd_folded; }
+extern "C" int dvlp_dev_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
 
 // `workspace` (B*H*F*66 floats) + `cls_stats` (B*H*4 floats), both optional: space mode, bf16 -- the CLS query is folded into the
-// frame waves and its global softmax statistics are kept in `cls_stats` for dvlp_attention_bwd.  dvlp_attention_fwd_folded() says
-// whether that happened (shape outside the fold's range, fp32, or the fold switched off: `cls_stats` is left untouched).
-extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
-                                  const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
-                                  float* cls_stats, void* stream) {
+// frame waves and its global softmax statistics are kept in `cls_stats` for dvlp_attention_bwd.  ext->folded says whether that
+// happened (shape outside the fold's range, fp32, or the fold switched off: `cls_stats` is left untouched).
+extern "C" int dvlp_attention_fwd_ex(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                                     const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
+                                     float* cls_stats, dvlp_attn_ext* ext, void* stream) {
     dvlp_clear_status();
-    t_attn_fwd_folded = 0;
+    if (ext) ext->folded = 0;
     AttnArgs a{};
     a.abl = g_attn_abl;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.out = out; a.ldo = ldo;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
-    a.keep = mode == 1 ? t_keep : nullptr; a.keepT = mode == 1 ? t_keepT : nullptr; a.kscale = t_kscale; a.Ns = (int)((N + 15) / 16 * 16);
-    t_keep = nullptr; t_keepT = nullptr; t_kscale = 1.f;
+    a.keep = (mode == 1 && ext) ? (const uint8_t*)ext->keep : nullptr; a.keepT = (mode == 1 && ext) ? (const uint8_t*)ext->keepT : nullptr;
+    a.kscale = (mode == 1 && ext && ext->keep) ? ext->keep_scale : 1.f; a.Ns = (int)((N + 15) / 16 * 16);
     if (int rc = attn_check(a)) return rc;
     const int nseg = mode == 0 ? (int)F : 1, nk = (int)R + (mode == 0 ? 1 : 0);
     size_t lds = (size_t)(2 * nk * KP + KMAX) * sizeof(float);
@@ -1358,7 +1354,7 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
         if (mode == 0) {
             const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
             // fold: the CLS row needs a free query slot in the frame tile (R + 1 <= 16 nqt)
-            if (workspace && cls_stats && g_attn_fold && nqt == nkt && nqt <= 3) {
+            if (ext && workspace && cls_stats && g_attn_fold && nqt == nkt && nqt <= 3) {     // (ext: the caller must be able to learn that it happened)
                 a.cls_o = workspace; a.cls_st = workspace + B * H * F * HD; a.cls_stats = cls_stats;
             }
             if (nqt == 3 && nkt == 3) MFWD(3, 3, B * H * F, 1);
@@ -1366,7 +1362,7 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
             else if (nqt == 1 && nkt == 1) MFWD(1, 1, B * H * F, 1);
             else if (nqt == 1 && nkt == 2) MFWD(1, 2, B * H * F, 1);
             else if (nqt == 2 && nkt == 3) MFWD(2, 3, B * H * F, 1);
-            if (done && a.cls_o) { hipLaunchKernelGGL(attn_fwd_cls_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(64), 0, st, a); t_attn_fwd_folded = 1; }
+            if (done && a.cls_o) { hipLaunchKernelGGL(attn_fwd_cls_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(64), 0, st, a); if (ext) ext->folded = 1; }
             else if (done) {   // CLS query on the streaming VALU workgroup
                 AttnArgs c = a; c.seg_begin = nseg;
                 hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(1, (unsigned)H, (unsigned)B), block, lds, st, c);
@@ -1385,20 +1381,20 @@ extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int
 
 // workspace (space mode only): fp32 [B*H*(F*3*64 + 4)]; `fwd_out` / `cls_stats`: the forward's output and the CLS statistics it saved
 // (dvlp_attention_fwd with workspaces), both optional
-extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
-                                  const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk,
-                                  void* dv, int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out,
-                                  const float* cls_stats, void* stream) {
+extern "C" int dvlp_attention_bwd_ex(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                                     const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk,
+                                     void* dv, int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out,
+                                     const float* cls_stats, dvlp_attn_ext* ext, void* stream) {
     dvlp_clear_status();
     AttnArgs a{};
     a.abl = g_attn_abl;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.addmask = addmask; a.dout = dout; a.ldo = ldo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd;
     a.ws = workspace;
     a.B = (int)B; a.N = (int)N; a.H = (int)H; a.F = (int)F; a.R = (int)R; a.mode = mode; a.scale = scale;
-    a.keep = mode == 1 ? t_keep : nullptr; a.keepT = mode == 1 ? t_keepT : nullptr; a.kscale = t_kscale; a.Ns = (int)((N + 15) / 16 * 16);
-    t_keep = nullptr; t_keepT = nullptr; t_kscale = 1.f;
-    float* const csum_dst = t_attn_csum_next;
-    t_attn_csum_next = nullptr; t_attn_csum_fused = 0;
+    a.keep = (mode == 1 && ext) ? (const uint8_t*)ext->keep : nullptr; a.keepT = (mode == 1 && ext) ? (const uint8_t*)ext->keepT : nullptr;
+    a.kscale = (mode == 1 && ext && ext->keep) ? ext->keep_scale : 1.f; a.Ns = (int)((N + 15) / 16 * 16);
+    float* const csum_dst = ext ? ext->colsum : nullptr;
+    if (ext) ext->colsum_fused = 0;
     if (int rc = attn_check(a)) return rc;
     if (mode == 0 && !workspace) return DVLP_ERR_SHAPE;
     const int nseg = mode == 0 ? (int)F : 1, nk = (int)R + (mode == 0 ? 1 : 0);
@@ -1425,7 +1421,7 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
                 a.fwd_out = fwd_out; a.ld_fo = ld_fwd_out; a.dq_ws = workspace + B * H * F * 2 * HD + B * H * 4;
                 if (csum_dst) {      // the CLS rows reach the partial buffer through the closing launch, which needs dq_cls: this form only
                     a.csum = dvlp_rd_reserve_push(B * F + B, 3 * H * HD, csum_dst);
-                    t_attn_csum_fused = a.csum != nullptr;
+                    if (ext) ext->colsum_fused = a.csum != nullptr;
                 }
             } else hipLaunchKernelGGL(attn_bwd_cls_pre_kernel<bf16>, grid2, block, lds2, st, a, stats);
 #define MMRG(NT_) hipLaunchKernelGGL((mattn_bwd_space_merged_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, \
@@ -1462,4 +1458,19 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
         if (mode == 0) hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16>, grid2, block, lds2, st, a);
     } else return DVLP_ERR_DTYPE;
     return dvlp_launch_status();
+}
+
+// the plain forms: no extras
+extern "C" int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                                  const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
+                                  float* cls_stats, void* stream) {
+    // without an extension struct the caller cannot learn whether the fold happened: the plain form never folds (cls_stats untouched)
+    return dvlp_attention_fwd_ex(dtype, mode, B, N, H, F, R, q, k, v, ld, addmask, out, ldo, scale, workspace, cls_stats, nullptr, stream);
+}
+extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                                  const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk,
+                                  void* dv, int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out,
+                                  const float* cls_stats, void* stream) {
+    return dvlp_attention_bwd_ex(dtype, mode, B, N, H, F, R, q, k, v, ld, addmask, dout, ldo, dq, dk, dv, ldd, workspace, scale, fwd_out, ld_fwd_out, cls_stats,
+                                 nullptr, stream);
 }

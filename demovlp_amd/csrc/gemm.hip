@@ -1437,25 +1437,25 @@ extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipE
 
 // A/B switch between the LDS-DMA kernel (default) and the register-staged one (tools/gemm_bench.py --variant)
 static int g_ablate = 0;         // tools/gemm_bench.py --ablate: 1 skip LDS-DMA issue, 2 skip LDS fragment reads, 4 skip MFMAs (TIMING ONLY)
-extern "C" int dvlp_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
 static bool g_use_glds = true;
 static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: measured no faster on this path's shapes), 1: heuristic, 2: always
-extern "C" int dvlp_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
 static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile patches pinned to XCDs (operand panels shared through L2), 0 = per-problem tile order
-extern "C" int dvlp_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
+extern "C" int dvlp_dev_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
-extern "C" int dvlp_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
 static int g_p8_persist = 1;     // persistent form of the 256-row kernel on multi-round outputs: 0 off, 1 on (default; A/B: tools/p8p_bench.py)
-extern "C" int dvlp_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
 static int g_p8_short = 1;       // 224-row tiles of the 256-row kernel: 0 never, 1 where they save CU-rounds (default), 2 whenever allowed
-extern "C" int dvlp_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
 static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
-extern "C" int dvlp_gemm_force_split(int s) { g_force_split = s; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_force_split(int s) { g_force_split = s; return DVLP_OK; }
 static int g_wgrad_split = 0;    // grouped weight gradients: 0 = automatic uniform K split, > 0 = forced
-extern "C" int dvlp_wgrad_group_split(int s) { g_wgrad_split = s; return DVLP_OK; }
+extern "C" int dvlp_dev_wgrad_group_split(int s) { g_wgrad_split = s; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
-extern "C" int dvlp_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
-extern "C" int dvlp_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
+extern "C" int dvlp_dev_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
 
 // caller-provided scratch for split-K slabs (dvlp_set_workspace); nullptr disables splitting
 // One scratch buffer per stream (two GEMMs in flight on different streams must not share slabs); stream 0 entry is the
@@ -1524,21 +1524,25 @@ extern "C" int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t*
     return DVLP_OK;
 }
 
-// ---- column sums of the NEXT GEMM's output (dvlp_gemm_colsum_next): the bias gradient of the Linear that consumes it ----
+// ---- column sums of a GEMM's output (dvlp_gemm_ex, dvlp_gemm_ext::colsum): the bias gradient of the Linear that consumes it ----
 float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out);      // norm.hip: deferred-reduction queue
 extern "C" int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int64_t inner, int64_t ostride, int64_t groups,
                            int64_t gstride, float* out, float* workspace, int accumulate, void* stream);
 extern "C" int64_t dvlp_colsum_chunks(int64_t M);
-static thread_local float* t_colsum_next = nullptr;
-extern "C" int dvlp_gemm_colsum_next(float* dst) { t_colsum_next = dst; return DVLP_OK; }
+// Optional extras of dvlp_gemm_ex (include/demovlp_hip.h: dvlp_gemm_ext), handed to the call that consumes them (rounds 2-3 armed the
+// column-sum request through a thread-local "next call" setter: an exception between the two calls left a stale pointer armed).
+struct dvlp_gemm_ext {
+    float* colsum;          // fp32 [N]: column sums of the stored output C wanted here (batch 1, not for fp32 outputs), or NULL
+    int colsum_fused;       // out: 1 = queued from inside the GEMM's epilogue (final after the deferred reductions are flushed), 0 = a plain pass ran
+};
 
-extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
-                                 const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
-                                 void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
-                                 int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream) {
+static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                             const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                             void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
+                             int64_t strideC, int64_t strideRes, int64_t strideAux, dvlp_gemm_ext* ext, void* stream) {
     dvlp_clear_status();
-    float* const csum_dst = t_colsum_next;      // column sums of this GEMM's output requested (dvlp_gemm_colsum_next)
-    t_colsum_next = nullptr;
+    float* const csum_dst = ext ? ext->colsum : nullptr;      // column sums of this GEMM's output requested
+    if (ext) ext->colsum_fused = 0;
     bool csum_fused = false;
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return DVLP_ERR_SHAPE;
     if ((flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD)) && !aux) return DVLP_ERR_SHAPE;
@@ -1682,6 +1686,7 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
         return DVLP_ERR_DTYPE;
     }
     if (g_prof) { (void)hipEventRecord(rec.b, st); g_recs.push_back(rec); }
+    if (ext) ext->colsum_fused = csum_fused ? 1 : 0;
     if (csum_dst && !csum_fused) {            // not fused: a plain column-sum pass over the stored output (batch 1 only)
         if (int rc = dvlp_launch_status()) return rc;
         const WsEntry w2 = ws_for(stream);
@@ -1691,11 +1696,27 @@ extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, i
     return dvlp_launch_status();
 }
 
+extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                                 const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                                 void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
+                                 int64_t strideC, int64_t strideRes, int64_t strideAux, void* stream) {
+    return gemm_batched_impl(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldres, aux, ldaux, flags, alpha, batch, strideA, strideB,
+                             strideC, strideRes, strideAux, nullptr, stream);
+}
+
 extern "C" int dvlp_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                          const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
                          void* aux, int64_t ldaux, int flags, float alpha, void* stream) {
-    return dvlp_gemm_batched(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldres, aux, ldaux, flags, alpha, 1, 0, 0,
-                             0, 0, 0, stream);
+    return gemm_batched_impl(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldres, aux, ldaux, flags, alpha, 1, 0, 0,
+                             0, 0, 0, nullptr, stream);
+}
+
+// dvlp_gemm with extras (dvlp_gemm_ext; NULL = none)
+extern "C" int dvlp_gemm_ex(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                            const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
+                            void* aux, int64_t ldaux, int flags, float alpha, dvlp_gemm_ext* ext, void* stream) {
+    return gemm_batched_impl(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldres, aux, ldaux, flags, alpha, 1, 0, 0,
+                             0, 0, 0, ext, stream);
 }
 
 // Weight gradients of several linears in one go: dW_p[M_p, N_p] (fp32, contiguous) (+)= dY_p[K_p, M_p]^T X_p[K_p, N_p].

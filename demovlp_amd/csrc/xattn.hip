@@ -37,14 +37,14 @@ struct XLayout {
 };
 static size_t pair_lds(int64_t G, int64_t W, int bwd);
 static bool g_force_general = false;
-extern "C" int dvlp_xattn_force_general(int on) { g_force_general = on != 0; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_force_general(int on) { g_force_general = on != 0; return DVLP_OK; }
 // fused per-pair kernels (xfused.hip): bf16, G <= 288, W <= 112
 bool dvlp_xfused_ok(int64_t G, int64_t W);
 int64_t dvlp_xfused_workspace_bytes(int64_t Bi, int64_t Bj, int64_t G, int64_t W);
 int dvlp_xfused_fwd(int64_t Bi, int64_t Bj, int64_t G, int64_t W, const void* Craw, const void* Qraw, const float* mimg, const float* mcap,
                     float lam, int gate, float* scores, void* workspace, hipStream_t st);
 static int g_fused = 1;          // 1 (default): use the fused kernels where they apply; 0: always the multi-kernel path (A/B, tests)
-extern "C" int dvlp_xattn_fused_mode(int mode) { g_fused = mode; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_fused_mode(int mode) { g_fused = mode; return DVLP_OK; }
 static bool x_fused(int dtype, int64_t G, int64_t W, int bwd) {
     return g_fused && !g_force_general && dtype == DVLP_BF16 && !bwd && dvlp_xfused_ok(G, W);
 }
@@ -58,10 +58,10 @@ static bool x_general(int64_t G, int64_t W) { return g_force_general || pair_lds
 // Replaces two [.,d]-wide batched products, the wc2 half of the cosine passes and two backward products by one [Bi*G, W] x [W, W]
 // product per caption, two passes over [B,B,G,W] tiles that exist anyway, and W x W products.
 static int g_gram = getenv("DVLP_XATTN_NO_GRAM") ? 0 : 1;
-extern "C" int dvlp_xattn_gram(int on) { g_gram = on; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_gram(int on) { g_gram = on; return DVLP_OK; }
 static int g_xbwd_packed_fwd();       // (defined below: the Gram form needs the bf16 backward kernel)
 static int g_pairg = 1;          // bf16 backward: dP1 columns in xperm_g order (A/B, tests)
-extern "C" int dvlp_xattn_pair_regions(int on) { g_pairg = on; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_pair_regions(int on) { g_pairg = on; return DVLP_OK; }
 static bool x_pairg(int dtype, int64_t G, int64_t W) { return g_pairg && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G >= 128; }
 static bool x_gram(int dtype, int64_t G, int64_t W) { return g_gram && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G <= 64 * 6; }
 
@@ -1237,10 +1237,10 @@ static void launch_pair_w(bool bwd, int nkw, dim3 grid, size_t lds, hipStream_t 
 #undef XLAUNCH
 }
 static int g_xstop = 0;
-extern "C" int dvlp_xattn_bwd_stop(int stage) { g_xstop = stage; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_bwd_stop(int stage) { g_xstop = stage; return DVLP_OK; }
 static int g_xbwd_packed = 1;    // bf16 backward: 1 = xsoftmax_bwd_bf16_kernel, 0 = the generic kernel (A/B, tests)
 static int g_xbwd_packed_fwd() { return g_xbwd_packed; }
-extern "C" int dvlp_xattn_bwd_variant(int packed) { g_xbwd_packed = packed; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_bwd_variant(int packed) { g_xbwd_packed = packed; return DVLP_OK; }
 static size_t pair_lds_bf16_bwd(int64_t G, int64_t W) {
     const int64_t Wq = W | 1;
     return (size_t)(G * Wq + G + W + 8 * W + G + W + 16 * G + 32 * 32 * cdiv(rup(W, 8), 32)) * sizeof(float);
@@ -1281,9 +1281,9 @@ static void launch_pair(bool bwd, int nkg, int nkw, dim3 grid, size_t lds, hipSt
 // The two directions of the loss (image->text / text->image) are independent between the softmax stages, and their contractions and
 // cosine passes are HBM-streaming kernels that reach 2.3-3.2 TB/s alone: the text->image half is issued on an internal side stream
 // beside the image->text half (fork / join by events -- legal inside a hipGraph capture), so the pair fills the memory system.
-// OFF by default (dvlp_xattn_parallel_halves(1) / DVLP_XATTN_PARALLEL=1 switch it on).
+// OFF by default (dvlp_dev_xattn_parallel_halves(1) / DVLP_XATTN_PARALLEL=1 switch it on).
 static int g_xpar = getenv("DVLP_XATTN_PARALLEL") ? 1 : 0;     // opt-in: -0.2 ms on the B = 64 backward alone, within noise in the step
-extern "C" int dvlp_xattn_parallel_halves(int on) { g_xpar = on; return DVLP_OK; }
+extern "C" int dvlp_dev_xattn_parallel_halves(int on) { g_xpar = on; return DVLP_OK; }
 struct XFork {
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;

@@ -44,9 +44,20 @@ def require_gpu(*tensors):
 # ----------------------------------------------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------------------------------------------
+class GemmExt(ctypes.Structure):
+    """include/demovlp_hip.h: dvlp_gemm_ext"""
+    _fields_ = [("colsum", ctypes.c_void_p), ("colsum_fused", ctypes.c_int)]
+
+
+class AttnExt(ctypes.Structure):
+    """include/demovlp_hip.h: dvlp_attn_ext"""
+    _fields_ = [("keep", ctypes.c_void_p), ("keepT", ctypes.c_void_p), ("keep_scale", ctypes.c_float), ("colsum", ctypes.c_void_p),
+                ("colsum_fused", ctypes.c_int), ("folded", ctypes.c_int)]
+
+
 def gemm(a, b, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, out=None, ldc=None, bias=None, res=None,
-         aux=None, flags=0, alpha=1.0, out_f32=False, dtype=None):
-    """C[M,N] = epi(alpha * op(A) op(B)^T).  a/b/out/res/aux are tensors whose data_ptr is the matrix origin."""
+         aux=None, flags=0, alpha=1.0, out_f32=False, dtype=None, ext=None):
+    """C[M,N] = epi(alpha * op(A) op(B)^T).  a/b/out/res/aux are tensors whose data_ptr is the matrix origin.  ``ext``: a GemmExt."""
     d = dt(a) if dtype is None else dtype
     if d == BF16:
         ensure_gemm_workspace(a.device)
@@ -57,6 +68,10 @@ def gemm(a, b, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, out
     ldc = ldc if ldc is not None else N
     if out_f32:
         flags |= EPI_OUT_F32
+    if ext is not None:
+        call("dvlp_gemm_ex", d, int(trans_a), int(trans_b), M, N, K, p(a), lda, p(b), ldb, p(out), ldc, p(bias), p(res),
+             N if res is not None else 0, p(aux), N if aux is not None else 0, flags, float(alpha), ctypes.byref(ext), stream())
+        return out
     call("dvlp_gemm", d, int(trans_a), int(trans_b), M, N, K, p(a), lda, p(b), ldb, p(out), ldc, p(bias), p(res),
          N if res is not None else 0, p(aux), N if aux is not None else 0, flags, float(alpha), stream())
     return out
@@ -171,11 +186,12 @@ def linear_bwd_input(dy2d, w, *, res=None, gelu_pre=None, relu_pre=None, out=Non
     if accumulate:
         flags |= EPI_ACCUM
     # A = dy [M x N] (k = N contiguous), B(kin, n) = W[n][kin] -> form R with ld = K
+    ext = None
     if colsum_to is not None:
         assert colsum_to.dtype == torch.float32 and colsum_to.numel() == K and not accumulate
         ensure_gemm_workspace(dy2d.device)
-        call("dvlp_gemm_colsum_next", p(colsum_to))
-    return gemm(dy2d, w, M, K, N, trans_b=True, ldb=K, bias=None, res=res, aux=aux, flags=flags, out=out)
+        ext = GemmExt(colsum=colsum_to.data_ptr())
+    return gemm(dy2d, w, M, K, N, trans_b=True, ldb=K, bias=None, res=res, aux=aux, flags=flags, out=out, ext=ext)
 
 
 def linear_bwd_weight(dy2d, x2d, out=None):
@@ -347,10 +363,11 @@ def space_attention_fwd(qkv, addmask, B, F, R, want_stats=False):
     if want_stats and qkv.dtype == torch.bfloat16 and (R + 15) // 16 == (R + 16) // 16 and R + 1 <= 48:
         stats = torch.empty((B, HEADS, 4), device=qkv.device, dtype=torch.float32)
         ws = _workspace("attn_fwd", B * HEADS * F * 66, qkv.device)
-    call("dvlp_attention_fwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(base), ctypes.c_void_p(base + 768 * es),
-         ctypes.c_void_p(base + 1536 * es), 2304, p(addmask), p(out), 768, SCALE, p(ws), p(stats), stream())
-    if stats is not None and not _lib.load().dvlp_attention_fwd_folded():
-        stats = None                                  # the fold was switched off (dvlp_attention_cls_fold): nothing was written
+    ext = AttnExt()
+    call("dvlp_attention_fwd_ex", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(base), ctypes.c_void_p(base + 768 * es),
+         ctypes.c_void_p(base + 1536 * es), 2304, p(addmask), p(out), 768, SCALE, p(ws), p(stats), ctypes.byref(ext), stream())
+    if stats is not None and not ext.folded:
+        stats = None                                  # the fold was switched off (dvlp_dev_attention_cls_fold): nothing was written
     return (out, stats) if want_stats else out
 
 
@@ -365,13 +382,12 @@ def space_attention_bwd(qkv, addmask, dout, B, F, R, out=None, stats=None, colsu
     ws = _workspace("attn", B * HEADS * (F * 3 * 64 + 4), qkv.device)
     if stats is None:
         out = None
-    if colsum_to is not None:
-        call("dvlp_attention_bwd_colsum_next", p(colsum_to))
-    call("dvlp_attention_bwd", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(b), ctypes.c_void_p(b + 768 * es),
+    ext = AttnExt(colsum=colsum_to.data_ptr() if colsum_to is not None else None)
+    call("dvlp_attention_bwd_ex", dt(qkv), 0, B, N, HEADS, F, R, ctypes.c_void_p(b), ctypes.c_void_p(b + 768 * es),
          ctypes.c_void_p(b + 1536 * es), 2304, p(addmask), p(dout), 768, ctypes.c_void_p(db), ctypes.c_void_p(db + 768 * es),
-         ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, p(out), 768, p(stats), stream())
+         ctypes.c_void_p(db + 1536 * es), 2304, p(ws), SCALE, p(out), 768, p(stats), ctypes.byref(ext), stream())
     if colsum_to is not None:
-        return dqkv, bool(_lib.load().dvlp_attention_bwd_colsum_fused())
+        return dqkv, bool(ext.colsum_fused)
     return dqkv
 
 
@@ -380,21 +396,19 @@ def full_attention_fwd(q, k, v, addmask, B, L, ld=768, keep=None):
     ``keep``: (keep bytes [B*H, Ns, Ns], transposed keep bytes, 1 / (1 - p)) from :func:`attn_keep_masks` -- dropout of the
     attention probabilities."""
     out = torch.empty((B * L, 768), device=q.device, dtype=q.dtype)
-    if keep is not None:
-        call("dvlp_attention_dropout_next", p(keep[0]), p(keep[1]), float(keep[2]))
-    call("dvlp_attention_fwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(out), 768, SCALE, None, None, stream())
+    ext = AttnExt(keep=keep[0].data_ptr(), keepT=keep[1].data_ptr(), keep_scale=float(keep[2])) if keep is not None else AttnExt()
+    call("dvlp_attention_fwd_ex", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(out), 768, SCALE, None, None, ctypes.byref(ext), stream())
     return out
 
 
 def full_attention_bwd(q, k, v, addmask, dout, B, L, ld=768, out=None, ld_out=768, keep=None):
-    if keep is not None:
-        call("dvlp_attention_dropout_next", p(keep[0]), p(keep[1]), float(keep[2]))
+    ext = AttnExt(keep=keep[0].data_ptr(), keepT=keep[1].data_ptr(), keep_scale=float(keep[2])) if keep is not None else AttnExt()
     if out is None:
         dq, dk, dv = (torch.empty((B * L, 768), device=q.device, dtype=q.dtype) for _ in range(3))
     else:
         dq, dk, dv = out
-    call("dvlp_attention_bwd", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
-         ld_out, None, SCALE, None, 0, None, stream())
+    call("dvlp_attention_bwd_ex", dt(q), 1, B, L, HEADS, 1, L, p(q), p(k), p(v), ld, p(addmask), p(dout), 768, p(dq), p(dk), p(dv),
+         ld_out, None, SCALE, None, 0, None, ctypes.byref(ext), stream())
     return dq, dk, dv
 
 

@@ -23,6 +23,10 @@ extern "C" {
 
 enum { DVLP_F32 = 0, DVLP_BF16 = 1 };
 enum { DVLP_OK = 0, DVLP_ERR_DTYPE = -1, DVLP_ERR_SHAPE = -2, DVLP_ERR_LAUNCH = -3, DVLP_ERR_UNSUPPORTED = -4 };
+/* ---- Naming: entry points called `dvlp_dev_*` are DEVELOPER switches (A/B measurements, timing ablations, tests that force a code path).
+ *      They set process-global state, are not part of the drop-in surface, and no product code calls them; every other entry point is
+ *      stateless apart from caller-registered scratch (dvlp_set_workspace*, dvlp_reduce_*) -- optional per-call extras travel in the
+ *      `dvlp_*_ext` structs of the `*_ex` calls, never through "next call" setters. ---- */
 /* dvlp_gemm epilogue flags */
 enum { DVLP_EPI_GELU = 1, DVLP_EPI_GELU_BWD = 2, DVLP_EPI_RELU_BWD = 4, DVLP_EPI_ACCUM = 8, DVLP_EPI_LEAKY = 16,
        DVLP_EPI_OUT_F32 = 32 /* C is fp32 whatever the compute dtype (weight gradients) */ };
@@ -48,36 +52,42 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
 /* K split of dvlp_gemm's bf16 kernels: 0 (default) = automatic, > 0 = forced -- for A/B measurements (tools/gemm_sweep.py) */
-int dvlp_gemm_force_split(int s);
+int dvlp_dev_gemm_force_split(int s);
 /* K split of the grouped weight-gradient launch: 0 (default) = automatic (the same split for every problem), > 0 = forced -- for
    A/B measurements (tools/wgrad_bench.py) */
-int dvlp_wgrad_group_split(int s);
-/* The next dvlp_gemm issued by this host thread also produces dst[N] (fp32) = column sums of its stored output C -- e.g. the bias
-   gradient of fc1 out of the GEMM that computes d(pre-activation).  Fused into the 256 x 256 kernel's epilogue when the deferred
-   reductions (dvlp_reduce_defer) are on -- final after dvlp_reduce_flush --, otherwise a dvlp_colsum pass right after the GEMM
-   (needs the split-K workspace as scratch). */
-int dvlp_gemm_colsum_next(float* dst);
+int dvlp_dev_wgrad_group_split(int s);
+/* dvlp_gemm with optional extras, handed to the call that consumes them (NULL = none).  `colsum`: fp32 dst[N] = column sums of the stored
+   output C -- e.g. the bias gradient of the Linear whose output gradient this product is (batch 1, not for fp32 outputs).  Fused into the
+   256-row kernel's epilogue through the deferred-reduction queue where possible (final after dvlp_reduce_flush; colsum_fused = 1),
+   otherwise a plain column-sum pass runs behind the product (colsum_fused = 0; final when the call's work is). */
+typedef struct dvlp_gemm_ext {
+    float* colsum;
+    int colsum_fused;      /* out */
+} dvlp_gemm_ext;
+int dvlp_gemm_ex(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                 int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres, void* aux, int64_t ldaux,
+                 int flags, float alpha, dvlp_gemm_ext* ext, void* stream);
 /* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
-int dvlp_gemm_variant(int use_lds_dma);
+int dvlp_dev_gemm_variant(int use_lds_dma);
 /* TIMING-ONLY ablation of the LDS-DMA kernel's K loop (1 no DMA, 2 no fragment reads, 4 no MFMA); 0 in production */
-int dvlp_gemm_ablate(int bits);
+int dvlp_dev_gemm_ablate(int bits);
 /* 256 x 128 tile of the LDS-DMA kernel: 0 never, 1 heuristic (default), 2 always -- for A/B measurements */
-int dvlp_gemm_wide_mode(int mode);
+int dvlp_dev_gemm_wide_mode(int mode);
 /* 256 x 256 ping-pong kernel (8 waves, counted-vmcnt LDS-DMA prefetch): 0 never, 1 where the grid suits it, 2 whenever the
    operands allow -- for A/B measurements and tests */
-int dvlp_gemm_p8_mode(int mode);
+int dvlp_dev_gemm_p8_mode(int mode);
 /* tile height of that kernel: 224-row tiles (the upper half of a tile 96 rows instead of 128) where they fill the CUs' rounds better than
    256-row ones -- 0 never, 1 (default) where rounds x rows is smaller, 2 whenever the operands allow; for A/B measurements and tests */
-int dvlp_gemm_p8_short_tiles(int mode);
+int dvlp_dev_gemm_p8_short_tiles(int mode);
 /* persistent form of that kernel on outputs of more than one round of tiles (one workgroup per CU walks its tiles; the next tile's first
    units are staged by the previous tile's last phases, the epilogue's stores are not waited for): 0 (default) off, 1 on -- for A/B
    measurements (tools/p8p_bench.py) and tests */
-int dvlp_gemm_p8_persistent(int mode);
+int dvlp_dev_gemm_p8_persistent(int mode);
 /* grouped weight gradients: 1 (default) blocks are dealt to the XCDs as 3 x 3 tile patches of one K slice, so a patch's operand panels are
    fetched into that XCD's L2 once; 0: per-problem tile order -- for A/B measurements */
-int dvlp_wgrad_group_patches(int on);
+int dvlp_dev_wgrad_group_patches(int on);
 /* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
-int dvlp_gemm_splitk_target(int64_t n);
+int dvlp_dev_gemm_splitk_target(int64_t n);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */
 int dvlp_set_workspace(void* ptr, int64_t bytes);
 /* same, for one stream only (GEMMs running concurrently on two streams need separate slabs) */
@@ -88,14 +98,14 @@ int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 
 /* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the
    three-launch form -- for A/B measurements and tests. */
-int dvlp_attention_bwd_variant(int merged);
+int dvlp_dev_attention_bwd_variant(int merged);
 /* TIMING-ONLY ablation of the MFMA attention backward (1 no stores, 2 no exp, 4 stop after the softmax); 0 in production */
-int dvlp_attention_ablate(int bits);
+int dvlp_dev_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */
 int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,
                        void* y_relu, float* mean, float* rstd, void* stream);
 /* bf16, D = 768: 1 (default) half a wave per row with 16-byte accesses, 0 the generic row-per-wave kernel -- for A/B measurements */
-int dvlp_layernorm_wide(int on);
+int dvlp_dev_layernorm_wide(int on);
 int64_t dvlp_layernorm_bwd_blocks(int64_t M);
 /* dx_colsum (optional): fp32 [D] <- column sums of dx, i.e. the bias gradient of the Linear that dx feeds (nn.Linear backward
    after the LayerNorm's); produced by the same kernel on the deferred path, by a dvlp_colsum pass otherwise */
@@ -130,14 +140,28 @@ int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int
                        int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out, const float* cls_stats,
                        void* stream);
 /* 1 (default): fold the CLS query where workspaces are given; 0: separate CLS launches -- for A/B measurements and tests */
-int dvlp_attention_cls_fold(int on);
-/* 1 if the last dvlp_attention_fwd of this host thread folded the CLS query and filled `cls_stats` (only then hand them to the backward) */
-int dvlp_attention_fwd_folded(void);
-/* the NEXT dvlp_attention_bwd (mode 0) issued by this host thread also queues the column sums of dq | dk | dv (fp32 [3*H*64]: the gradient
-   of the packed qkv bias, object_transformer.py:310 qkv_bias=True) into `dst` through the deferred-reduction queue when it can (bf16 one-pass
-   form with the forward's statistics); dvlp_attention_bwd_colsum_fused() = 1 if the last call did, else the caller sums the columns itself */
-int dvlp_attention_bwd_colsum_next(float* dst);
-int dvlp_attention_bwd_colsum_fused(void);
+int dvlp_dev_attention_cls_fold(int on);
+/* The same two calls with optional extras, handed to the call that consumes them (ext may be NULL):
+     keep / keepT / keep_scale  (mode 1) dropout of the attention probabilities: keep bytes in both orientations from dvlp_dropout_attn_mask and
+                                1 / (1 - p) -- HF MultiHeadSelfAttention's `weights = dropout(softmax(scores))`
+     colsum                     (backward, mode 0) fp32 [3*H*64]: column sums of dq | dk | dv = the gradient of the packed qkv bias
+                                (object_transformer.py:310 qkv_bias=True), queued through the deferred-reduction queue when the call can
+                                (bf16 one-pass form with the forward's statistics): colsum_fused = 1; else the caller sums the columns itself
+     folded                     (forward, out) 1 if the CLS query was folded and `cls_stats` filled -- only then hand them to the backward.
+   The CLS fold needs `ext` (the caller must be able to learn whether `cls_stats` were written): the plain dvlp_attention_fwd never folds. */
+typedef struct dvlp_attn_ext {
+    const void* keep; const void* keepT; float keep_scale;
+    float* colsum;
+    int colsum_fused;      /* out */
+    int folded;            /* out */
+} dvlp_attn_ext;
+int dvlp_attention_fwd_ex(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                          const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
+                          float* cls_stats, dvlp_attn_ext* ext, void* stream);
+int dvlp_attention_bwd_ex(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
+                          const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk, void* dv,
+                          int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out, const float* cls_stats,
+                          dvlp_attn_ext* ext, void* stream);
 
 /* ---- tower prologues: ObjectTransformer.forward_features (object_transformer.py:400-433); DistilBERT embeddings ---- */
 int dvlp_obj_split(int dtype, int64_t M, const float* obj, void* feat, float* box, void* stream);
@@ -175,37 +199,35 @@ int dvlp_dropout_bwd(int dtype, int64_t n, const void* dy, const void* keep, flo
 /* keep bytes of the attention probabilities of BH = batch * heads [N x N] maps in both orientations: keep[bh][q][key] and
    keepT[bh][key][q], row stride N rounded up to 16 (pads 0) */
 int dvlp_dropout_attn_mask(int64_t BH, int64_t N, float p, const void* state, int site, void* keep, void* keepT, void* stream);
-/* the NEXT dvlp_attention_fwd / dvlp_attention_bwd (mode 1) issued by this host thread multiplies its probabilities by
-   keep * scale (scale = 1 / (1 - p)): HF MultiHeadSelfAttention's `weights = dropout(softmax(scores))` */
-int dvlp_attention_dropout_next(const void* keep, const void* keepT, float scale);
+/* (the masks reach the attention kernels through dvlp_attn_ext of dvlp_attention_fwd_ex / dvlp_attention_bwd_ex) */
 /* out[4] = Philox4x32-10(ctr_key[0..3], key = ctr_key[4..5]) computed on the device (known-answer test) */
 int dvlp_philox_kat(const void* ctr_key, void* out, void* stream);
 
 /* ---- local loss: xattn_score_fast / func_attention_fast / focal_equal / cosine_similarity (model/loss.py:209-330) ---- */
 /* testing knob: 1 = always take the general-G (long-video) softmax path, even when the fused per-pair kernels fit LDS */
-int dvlp_xattn_force_general(int on);
+int dvlp_dev_xattn_force_general(int on);
 /* 1 (default): bf16 pairs with F*R <= 288, W <= 112 run the fused per-pair kernels (everything between the embeddings and the
    score on chip); 0: always the multi-kernel path -- for A/B measurements and tests */
-int dvlp_xattn_fused_mode(int mode);
+int dvlp_dev_xattn_fused_mode(int mode);
 /* bf16 backward of the per-pair softmax stage: 1 (default) keeps both intermediate tiles on chip (LDS low halves / registers),
    0 runs the generic kernel that round-trips them through the workspace -- for A/B measurements and tests */
-int dvlp_xattn_bwd_variant(int packed);
+int dvlp_dev_xattn_bwd_variant(int packed);
 /* 1 (default): bf16 pairs that fit the per-pair LDS tile use the Gram form of the text->image direction -- cos(wc2_g, C_g) from
    u_g = sum_w P2 S_raw and v_g = P2_g (Q^ Q^^T) P2_g^T, so the [Bj][Bi][G][d] weighted contexts are never formed (forward or backward);
    0: the weighted contexts are materialised as in the reference -- for A/B measurements and tests */
-int dvlp_xattn_gram(int on);
+int dvlp_dev_xattn_gram(int on);
 /* 1 (default): bf16 backward with the per-pair LDS tile: the dP1 rows are produced with regions g and g + 64 of every full block of 128
    adjacent (the product is handed a row-permuted copy of the unit regions), so the backward fetches them as 4-byte pieces; 0: natural
    order -- for A/B measurements and tests */
-int dvlp_xattn_pair_regions(int on);
+int dvlp_dev_xattn_pair_regions(int on);
 /* 1: the text->image half of the local loss (its contractions and cosine passes) is issued on an internal side stream beside the
    image->text half between the softmax stages (fork / join by events, capturable); 0 (default): everything on the caller's stream */
-int dvlp_xattn_parallel_halves(int on);
+int dvlp_dev_xattn_parallel_halves(int on);
 /* TIMING-ONLY ablation of the bf16 per-pair backward kernel: leave after stage 6 (launch + dP1 rows requested), 5 (S tile staged), 1 (+ norms),
    2 (image->text pass), 3 (text->image pass); 0 in production (tools/xbwd_stages.py) */
-int dvlp_xattn_bwd_stop(int stage);
+int dvlp_dev_xattn_bwd_stop(int stage);
 /* TIMING-ONLY ablation of the fused forward kernel (stop after phase n); 0 in production */
-int dvlp_xfused_ablate(int stop);
+int dvlp_dev_xfused_ablate(int stop);
 int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd);
 int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                    const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd, void* stream);
@@ -220,7 +242,7 @@ int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, cons
                            float* dxs, float* losses, void* stream);
 /* 1 (default): bf16 embeddings with B = 32 / 64 run the three B x B x 256 products of the launch on the matrix cores; 0: the
  * one-wave-per-entry form used for every other shape -- for A/B measurements and tests */
-int dvlp_loss_mfma(int on);
+int dvlp_dev_loss_mfma(int on);
 
 /* rectangular sim_matrix (model/model.py:582-590 on [N,256] x [M,256], e.g. the whole eval set at trainer/trainer_dist.py:369):
    xn (fp32) = x / max(|x|, 1e-8) row-wise and norm = |x|; the [N,M] product and its two gradient products are dvlp_gemm calls in

@@ -39,11 +39,11 @@ P8_DEFAULT = 1
 def wide_mode(request):
     """Run the bf16 GEMM tests on every LDS-DMA tile variant (128x128 two-stage, 256x128 three-stage counted-vmcnt,
     256x256 ping-pong)."""
-    ops.call("dvlp_gemm_wide_mode", request.param[0])
-    ops.call("dvlp_gemm_p8_mode", request.param[1])
+    ops.call("dvlp_dev_gemm_wide_mode", request.param[0])
+    ops.call("dvlp_dev_gemm_p8_mode", request.param[1])
     yield request.param
-    ops.call("dvlp_gemm_wide_mode", 0)
-    ops.call("dvlp_gemm_p8_mode", P8_DEFAULT)
+    ops.call("dvlp_dev_gemm_wide_mode", 0)
+    ops.call("dvlp_dev_gemm_p8_mode", P8_DEFAULT)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -141,9 +141,9 @@ def test_colsum(dtype):
 def attn_bwd_variant(request):
     """bf16 space attention: the CLS query folded into the frame waves in forward AND backward (the forward's statistics handed to the
     backward: what VitBlockFn runs), the one-pass backward with its own statistics launch, and the three-launch backward."""
-    ops.call("dvlp_attention_bwd_variant", 1 if request.param else 0)
+    ops.call("dvlp_dev_attention_bwd_variant", 1 if request.param else 0)
     yield request.param
-    ops.call("dvlp_attention_bwd_variant", 1)
+    ops.call("dvlp_dev_attention_bwd_variant", 1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -174,23 +174,23 @@ def test_space_attention(dtype, B, F, R, attn_bwd_variant):
 
 
 def test_space_attention_fold_switched_off():
-    """dvlp_attention_cls_fold(0): the forward leaves `cls_stats` untouched, says so through dvlp_attention_fwd_folded(), and the host
-    hands no statistics to the backward (which then runs its own pass) -- never uninitialised ones."""
+    """dvlp_dev_attention_cls_fold(0): the forward leaves `cls_stats` untouched, says so in dvlp_attn_ext::folded, and the host hands no
+    statistics to the backward (which then runs its own pass) -- never uninitialised ones."""
     B, F, R = 2, 8, 36
     N = 1 + F * R
     qkv = rnd(B * N, 2304, dtype=torch.bfloat16, scale=1.5)
     addmask = torch.zeros(B, N, device=DEV)
     dout = rnd(B * N, 768, dtype=torch.bfloat16, seed=2)
     out1, st1 = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True)
-    assert st1 is not None and _lib.load().dvlp_attention_fwd_folded() == 1
+    assert st1 is not None
     d1 = ops.space_attention_bwd(qkv, addmask, dout, B, F, R, out=out1, stats=st1)
-    ops.call("dvlp_attention_cls_fold", 0)
+    ops.call("dvlp_dev_attention_cls_fold", 0)
     try:
         out0, st0 = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True)
-        assert st0 is None and _lib.load().dvlp_attention_fwd_folded() == 0
+        assert st0 is None
         d0 = ops.space_attention_bwd(qkv, addmask, dout, B, F, R, out=out0, stats=st0)
     finally:
-        ops.call("dvlp_attention_cls_fold", 1)
+        ops.call("dvlp_dev_attention_cls_fold", 1)
     assert rel(out0, out1) < 1e-2 and rel(d0, d1) < 2e-2
 
 
@@ -261,11 +261,11 @@ def test_text_embed(dtype):
 def test_xattn(dtype, Bi, Bj, G, W, gate, general):
     """general=True forces the long-video (general-G) softmax path on shapes the fused kernels also handle; G=1152 takes it
     by itself (the [G, W] tile no longer fits LDS)."""
-    ops.call("dvlp_xattn_force_general", int(general))
+    ops.call("dvlp_dev_xattn_force_general", int(general))
     try:
         _xattn_case(dtype, Bi, Bj, G, W, gate)
     finally:
-        ops.call("dvlp_xattn_force_general", 0)
+        ops.call("dvlp_dev_xattn_force_general", 0)
 
 
 def _xattn_case(dtype, Bi, Bj, G, W, gate):
@@ -344,11 +344,11 @@ def test_loss_heads_matrix_core_form(B):
     xs = (torch.rand(B, B, generator=torch.Generator().manual_seed(2)) * 0.3 + 0.4 + 0.2 * torch.eye(B)).to(DEV)
     r1 = ops.global_local_loss(a, b, xs, 0.05, 20.0, 1, 1, 7)
     r1 = {k: v.clone() for k, v in r1.items()}
-    ops.call("dvlp_loss_mfma", 0)
+    ops.call("dvlp_dev_loss_mfma", 0)
     try:
         r0 = ops.global_local_loss(a, b, xs, 0.05, 20.0, 1, 1, 7)
     finally:
-        ops.call("dvlp_loss_mfma", 1)
+        ops.call("dvlp_dev_loss_mfma", 1)
     assert float((r1["sim"] - r0["sim"]).abs().max()) < 2e-6
     assert float((r1["losses"] - r0["losses"]).abs().max()) < 1e-5 * float(r0["losses"].abs().max())
     for k in ("dgt", "dgo"):
@@ -397,7 +397,7 @@ def test_gemm_pingpong_race_screen(form):
     """The 256x256 kernel orders its LDS-DMA fills against its LDS reads with counted vmcnt waits and raw barriers only:
     screen for races by repeating launches at several K depths (1, 2, odd, long) and demanding bit-identical, correct
     results every time."""
-    ops.call("dvlp_gemm_p8_mode", 2)
+    ops.call("dvlp_dev_gemm_p8_mode", 2)
     try:
         for M, N, K in [(1024, 768, 64), (777, 512, 128), (2304, 1024, 448), (4096, 768, 3072)]:
             if form == "fwd":
@@ -419,7 +419,7 @@ def test_gemm_pingpong_race_screen(form):
             for _ in range(25):
                 assert torch.equal(run(), first)
     finally:
-        ops.call("dvlp_gemm_p8_mode", P8_DEFAULT)
+        ops.call("dvlp_dev_gemm_p8_mode", P8_DEFAULT)
 
 
 def test_deferred_reductions_match_immediate():
@@ -514,7 +514,7 @@ def test_region_batcher_ragged_files_match_reference_pipeline(tmp_path):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(4160, 768, 3072), (1000, 768, 768), (777, 520, 264)])
 def test_gemm_fused_column_sums(dtype, M, N, K):
-    """dvlp_gemm_colsum_next: column sums of the GEMM's stored output, fused into the 256-row epilogue on the deferred path and
+    """dvlp_gemm_ex with dvlp_gemm_ext::colsum: column sums of the GEMM's stored output, fused into the 256-row epilogue on the deferred path and
     by a plain pass otherwise -- both equal ops.colsum of the output."""
     dy, w, pre = rnd(M, N, dtype=dtype), rnd(N, K, dtype=dtype, seed=1, scale=0.05), rnd(M, K, dtype=dtype, seed=2)
     want = ops.linear_bwd_input(dy, w, gelu_pre=pre)

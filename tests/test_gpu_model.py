@@ -219,7 +219,7 @@ def _dp2_batch(F, R, B, rank):
             "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
 
 
-@pytest.mark.parametrize("overlap", [0, 2], ids=["one-stream", "wgrad-side-stream"])
+@pytest.mark.parametrize("overlap", [0, pytest.param(2, marks=pytest.mark.slow)], ids=["one-stream", "wgrad-side-stream"])
 def test_two_rank_data_parallel_step_matches_averaged_gradients(overlap):
     """The multi-GPU path on one GPU: two processes, each its own batch, GradReducer all-reducing arena buckets from the
     post-accumulate hooks (tail bucket after the deferred flush), 1/world folded into fused AdamW.  Both ranks must end

@@ -375,8 +375,9 @@ def test_bench_rccl_path_in_a_one_rank_group(graph, gather):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, DVLP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (the graph variant also carries its buckets as bf16 -- GraphedTrainStep(grad_dtype='bfloat16'): cast, RCCL sum in bf16, cast back)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline",
-           "--graph", str(graph)] + (["--gather-negatives"] if gather else [])
+           "--graph", str(graph)] + (["--gather-negatives"] if gather else []) + (["--grad-dtype", "bf16"] if graph else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:                   # one retry on a fresh port: process-group bring-up on a cold box is the only part not under our control
         print("first attempt failed:", r.stderr[-3000:])
@@ -387,6 +388,10 @@ def test_bench_rccl_path_in_a_one_rank_group(graph, gather):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["unit"] == "pairs/s" and out["value"] > 0 and out["scaling"] == "weak"
     assert out["per_rank_pairs_per_s"] and out["grad_allreduce_ms_standalone"] > 0
+    if graph:      # per-piece exchange times of the multi-graph step (three pieces at the default cuts), measured behind the timed region
+        px = out["grad_exchange_pieces"]
+        assert len(px) == 3 and all(e["ms"] > 0 and e["mb"] > 0 for e in px) and out["grad_exchange_dtype"] == "bf16"
+        assert abs(sum(e["mb"] for e in px) - out["grad_allreduce_bytes"] / 2 / 2 ** 20) < 2.0       # bf16: half the arena's bytes
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
     assert out["roofline"]["object_transformer_frac"] > 0
     assert np.isfinite(out["config"]["final_loss"])
@@ -530,10 +535,10 @@ def test_fused_local_loss_forward_vs_oracle(B, G, W, gate):
     res = {}
     try:
         for mode in (0, 1):
-            ops.call("dvlp_xattn_fused_mode", mode)
+            ops.call("dvlp_dev_xattn_fused_mode", mode)
             res[mode] = ops.xattn_fwd(C, Q, t(m_img), t(m_cap), 20.0, gate, False)[0].cpu().numpy()
     finally:
-        ops.call("dvlp_xattn_fused_mode", 1)
+        ops.call("dvlp_dev_xattn_fused_mode", 1)
     assert np.abs(res[1] - ref).max() < 2e-3, np.abs(res[1] - ref).max()
     assert np.abs(res[1] - res[0]).max() < 2e-3
 
@@ -568,15 +573,15 @@ def test_local_loss_bf16_on_chip_tiles_and_gram_form_vs_generic_and_oracle(B, G,
     res, sco = {}, {}
     try:
         for mode in (0, 1, 2):
-            ops.call("dvlp_xattn_bwd_variant", int(mode > 0))
-            ops.call("dvlp_xattn_gram", int(mode == 2))
+            ops.call("dvlp_dev_xattn_bwd_variant", int(mode > 0))
+            ops.call("dvlp_dev_xattn_gram", int(mode == 2))
             scores, ws = ops.xattn_fwd(C, Q, t(m_img), t(m_cap), 20.0, gate, True)
             sco[mode] = scores.cpu().numpy()
             dC, dQ = ops.xattn_bwd(C, Q, t(m_img), t(m_cap), 20.0, gate, t(dsc), ws)
             res[mode] = (dC.float().cpu().numpy(), dQ.float().cpu().numpy())
     finally:
-        ops.call("dvlp_xattn_bwd_variant", 1)
-        ops.call("dvlp_xattn_gram", 1)
+        ops.call("dvlp_dev_xattn_bwd_variant", 1)
+        ops.call("dvlp_dev_xattn_gram", 1)
     ref_s = sc.detach().numpy()
     for mode in (1, 2):
         assert np.abs(sco[mode] - ref_s).max() < 2e-3, (mode, np.abs(sco[mode] - ref_s).max())

@@ -111,20 +111,14 @@ def _graph_dp_worker(rank, world, port, q, cut):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), 6, None], ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "two-graphs-cut6", "one-graph"])
-def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
-    """Two processes on cuda:0, each with its own batch per step, five steps through GraphedTrainStep (two of them replays of the
-    captured graphs with the bucketed gradient exchange between / behind them and the fused optimizer applied bucket by bucket on
-    its own stream as each reduction completes).  The ranks' parameters must be bit-equal, and equal -- to
-    1e-5 of max|p| -- to one process that runs both batches, sums the gradients itself and steps with grad_scale 1/2."""
-    res = _spawn(_graph_dp_worker, (cut,))
-    (_, l0, p0, s0, info), (_, l1, p1, s1, _) = res
-    if isinstance(cut, tuple) and cut[-1] == "side-stream":
-        cut = cut[:-1]
-    assert info["captured"] and info["steps"] == NSTEP
-    assert info["graph2"] == (cut is not None) and (info["early"] >= 2 if cut is not None else info["early"] == 0)
-    assert info["graphs"] == (1 if cut is None else 2 if isinstance(cut, int) else len(cut) + 1)
-    assert np.array_equal(p0, p1) and s0 == s1                       # lock step, bit for bit
+_HAND_REF = []
+
+
+def _hand_averaged_reference():
+    """One process that runs both ranks' batches, sums the gradients itself and steps with grad_scale 1/2 (the same for every variant of the test
+    below: computed once)."""
+    if _HAND_REF:
+        return _HAND_REF[0]
     F, R, B = 8, 36, 2
     model = build(F, R)
     arena = ParamArena(model)
@@ -143,7 +137,26 @@ def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
         ref_losses.append(ls)
         arena.flat_g.copy_(acc)
         opt.step(grad_scale=0.5)
-    pref = arena.flat_p.double().cpu().numpy()[::211]
+    _HAND_REF.append((ref_losses, arena.flat_p.double().cpu().numpy()[::211]))
+    return _HAND_REF[0]
+
+
+@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), pytest.param(6, marks=pytest.mark.slow), None],
+                         ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "two-graphs-cut6", "one-graph"])
+def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
+    """Two processes on cuda:0, each with its own batch per step, five steps through GraphedTrainStep (two of them replays of the
+    captured graphs with the bucketed gradient exchange between / behind them and the fused optimizer applied bucket by bucket on
+    its own stream as each reduction completes).  The ranks' parameters must be bit-equal, and equal -- to
+    1e-5 of max|p| -- to one process that runs both batches, sums the gradients itself and steps with grad_scale 1/2."""
+    res = _spawn(_graph_dp_worker, (cut,))
+    (_, l0, p0, s0, info), (_, l1, p1, s1, _) = res
+    if isinstance(cut, tuple) and cut[-1] == "side-stream":
+        cut = cut[:-1]
+    assert info["captured"] and info["steps"] == NSTEP
+    assert info["graph2"] == (cut is not None) and (info["early"] >= 2 if cut is not None else info["early"] == 0)
+    assert info["graphs"] == (1 if cut is None else 2 if isinstance(cut, int) else len(cut) + 1)
+    assert np.array_equal(p0, p1) and s0 == s1                       # lock step, bit for bit
+    ref_losses, pref = _hand_averaged_reference()
     for s in range(NSTEP):
         for r, l in ((0, l0), (1, l1)):
             assert abs(l[s] - ref_losses[s][r]) < 1e-5 * max(1.0, abs(l[s])), (s, r, l[s], ref_losses[s][r])
@@ -363,7 +376,7 @@ def test_bf16_ten_step_loss_curve_through_graph_replay_vs_f64_curve(tag, lr):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(18496, 2304, 768), (18496, 768, 3072), (2000, 768, 768), (225, 256, 128), (6400, 3072, 768)])
 def test_gemm_short_tiles_bit_equal_to_256_row_tiles(M, N, K):
-    """dvlp_gemm_p8_short_tiles: every epilogue kind of the forward / dX products (bias, +residual, GELU with pre-activation out,
+    """dvlp_dev_gemm_p8_short_tiles: every epilogue kind of the forward / dX products (bias, +residual, GELU with pre-activation out,
     GELU' with pre-activation in and fused column sums) on 224-row tiles against 256-row tiles: identical bits, ragged last row
     tile included (18496 = 82 x 224 + 128; 2000 = 8 x 224 + 208; 225 = 224 + 1)."""
     g = torch.Generator(device=DEV).manual_seed(3)
@@ -374,13 +387,13 @@ def test_gemm_short_tiles_bit_equal_to_256_row_tiles(M, N, K):
     res = torch.randn(M, N, device=DEV, generator=g).to(bf)
     dy = torch.randn(M, N, device=DEV, generator=g).to(bf)
     pre = torch.randn(M, K, device=DEV, generator=g).to(bf)
-    ops.call("dvlp_gemm_p8_mode", 2)
-    ops.call("dvlp_gemm_p8_persistent", 0)          # tile height alone (the persistent form adds the bias first: its own test below)
+    ops.call("dvlp_dev_gemm_p8_mode", 2)
+    ops.call("dvlp_dev_gemm_p8_persistent", 0)          # tile height alone (the persistent form adds the bias first: its own test below)
     ops.enable_deferred_reductions(torch.device(DEV), workspace_mb=64)
     try:
         outs = []
         for mode in (0, 2):
-            ops.call("dvlp_gemm_p8_short_tiles", mode)
+            ops.call("dvlp_dev_gemm_p8_short_tiles", mode)
             aux = torch.empty(M, N, device=DEV, dtype=bf)
             cs = torch.zeros(K, device=DEV)
             o = [ops.linear_fwd(x, w, bias), ops.linear_fwd(x, w, bias, res=res), ops.linear_fwd(x, w, bias, gelu_aux=aux), aux,
@@ -394,9 +407,9 @@ def test_gemm_short_tiles_bit_equal_to_256_row_tiles(M, N, K):
         assert float((outs[1][0].float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
     finally:
         ops.disable_deferred_reductions()
-        ops.call("dvlp_gemm_p8_short_tiles", 1)
-        ops.call("dvlp_gemm_p8_mode", 1)
-        ops.call("dvlp_gemm_p8_persistent", 1)
+        ops.call("dvlp_dev_gemm_p8_short_tiles", 1)
+        ops.call("dvlp_dev_gemm_p8_mode", 1)
+        ops.call("dvlp_dev_gemm_p8_persistent", 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -420,11 +433,11 @@ def test_bf16_evaluate_runs_the_grid_on_the_fused_kernel_vs_reference_golden():
     n = BS * NB
     model = build(F, R, "bfloat16")
     res = evaluate(model, loss_head(), _eval_batches(F, R, BS, NB))
-    ops.call("dvlp_xattn_fused_mode", 0)
+    ops.call("dvlp_dev_xattn_fused_mode", 0)
     try:
         res_multi = evaluate(model, loss_head(), _eval_batches(F, R, BS, NB))
     finally:
-        ops.call("dvlp_xattn_fused_mode", 1)
+        ops.call("dvlp_dev_xattn_fused_mode", 1)
     res32 = evaluate(model, loss_head(), _eval_batches(F, R, BS, NB), precision="float32")      # bf16 towers, fp32 grid
     scale = np.abs(g["local_sims"]).max()
     d_fused = np.abs(res["local_sims"] - g["local_sims"]).max() / scale
@@ -502,7 +515,7 @@ def test_evaluate_mscoco_branch_subsamples_videos_and_passes_fold():
 
 @pytest.mark.parametrize("M,N,K", [(18496, 2304, 768), (18496, 3072, 256), (9000, 2304, 768), (30000, 768, 2304)])
 def test_persistent_gemm_kernel_agrees_with_the_one_tile_form(M, N, K):
-    """dvlp_gemm_p8_persistent (default on): one workgroup per CU walks its 224-row tiles, the next tile's first eight units are staged
+    """dvlp_dev_gemm_p8_persistent (default on): one workgroup per CU walks its 224-row tiles, the next tile's first eight units are staged
     across the tile boundary, accumulators start from the bias.  Same products in the same order; the bias enters the fp32 sum first
     instead of last, so outputs with a bias may differ by one bf16 rounding -- bounded here against an fp32 reference; without a
     bias (forward and dX forms) they are bit-equal.  Shapes: 4 / 12 / 36 K tiles, a ragged last row tile (9000 = 40 x 224 + 40), and a
@@ -517,7 +530,7 @@ def test_persistent_gemm_kernel_agrees_with_the_one_tile_form(M, N, K):
     try:
         outs = {}
         for mode in (0, 1):
-            ops.call("dvlp_gemm_p8_persistent", mode)
+            ops.call("dvlp_dev_gemm_p8_persistent", mode)
             aux = torch.empty(M, N, device=DEV, dtype=bf)
             outs[mode] = (ops.linear_fwd(x, w, bias), ops.linear_fwd(x, w, bias, gelu_aux=aux), aux, ops.linear_fwd(x, w, None), ops.linear_bwd_input(dy, w))
             if mode == 1:
@@ -532,7 +545,7 @@ def test_persistent_gemm_kernel_agrees_with_the_one_tile_form(M, N, K):
         dref = dy.float() @ w.float()
         assert float((outs[1][4].float() - dref).abs().max()) < 1e-2 * float(dref.abs().max())
     finally:
-        ops.call("dvlp_gemm_p8_persistent", 1)
+        ops.call("dvlp_dev_gemm_p8_persistent", 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

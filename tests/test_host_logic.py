@@ -382,3 +382,51 @@ def test_graphed_step_host_bookkeeping_bucket_alignment_and_lru():
     n_before = len(captured)
     st(batch(4))
     assert len(captured) == n_before                                               # still captured: replayed, not re-captured
+
+
+def _bf16_bucket_worker(rank, world, port, q):
+    import traceback
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from demovlp_amd.trainer import GraphedTrainStep
+        n = 64 * 300
+        gen = torch.Generator().manual_seed(100 + rank)
+        out = {}
+        for dtype in ("float32", "bfloat16"):
+            g = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank)) * 1e-3
+            arena = SimpleNamespace(ALIGN=64, total=n, flat_g=g)
+            st = GraphedTrainStep(SimpleNamespace(), None, SimpleNamespace(arena=arena), bucket_mb=64 * 40 * 4 / 2 ** 20, grad_dtype=dtype)
+            st.world, st.collective = world, True
+            st._exchange_and_update([(0, 64 * 100), (64 * 100, n)])
+            out[dtype] = g.clone()
+        q.put((rank, out["float32"].numpy(), out["bfloat16"].numpy()))
+    except BaseException:  # noqa: BLE001
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_buckets_gloo_world2():
+    """GraphedTrainStep(grad_dtype='bfloat16'), host path: every bucket is summed across the ranks in bf16 and lands back in the fp32
+    gradient buffer -- identical on both ranks, within bf16 rounding of the fp32 exchange (the optimizer's inputs stay fp32 tensors)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    (_, f0, h0), (_, f1, h1) = res
+    assert np.array_equal(f0, f1) and np.array_equal(h0, h1)                       # ranks in lock step either way
+    want = sum((torch.randn(64 * 300, generator=torch.Generator().manual_seed(100 + r)) * 1e-3) for r in range(2)).numpy()
+    assert np.abs(f0 - want).max() <= 1e-9
+    rel = np.abs(h0 - want).max() / np.abs(want).max()
+    assert 0 < rel < 2 ** -7, rel                                                  # bf16 inputs + a bf16 sum: three roundings of 2^-9

@@ -24,7 +24,7 @@ def bench(fn, iters=20):
 
 def main():
     if len(sys.argv) > 1:
-        ops.call("dvlp_attention_ablate", int(sys.argv[1]))
+        ops.call("dvlp_dev_attention_ablate", int(sys.argv[1]))
     B, F, R = 64, 8, 36
     N = 1 + F * R
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -33,7 +33,7 @@ def main():
     mask = torch.zeros(B, N, device="cuda")
     mb = 2.0 * B * N * 2304 / 1e6
     for fold in (0, 1):
-        ops.call("dvlp_attention_cls_fold", fold)
+        ops.call("dvlp_dev_attention_cls_fold", fold)
         out, stats = ops.space_attention_fwd(qkv, mask, B, F, R, want_stats=True)
         t = bench(lambda: ops.space_attention_fwd(qkv, mask, B, F, R, want_stats=True))
         print("CLS fold %d: space attention fwd  %7.1f us   (qkv read %.0f MB + out %.0f MB -> %.2f TB/s)" % (fold, t, mb, mb / 3, (mb + mb / 3) / t))

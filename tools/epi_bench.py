@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where a product's time goes (MI355X): the fc1 shape with each epilogue, and with the timing-only ablations of dvlp_gemm_ablate
+"""Where a product's time goes (MI355X): the fc1 shape with each epilogue, and with the timing-only ablations of dvlp_dev_gemm_ablate
 (8 = no stores, 16 = no epilogue at all).  python tools/epi_bench.py"""
 import ctypes
 import os
@@ -30,7 +30,7 @@ for N, K in ((3072, 768), (768, 768)):
                                      ("bias+gelu(+aux out)", bias, None, aux, 1), ("gelu_bwd(aux in)", None, None, aux, 2)):
         row = []
         for abl in (0, 8, 16, 32, 64):
-            lib.dvlp_gemm_ablate(abl)
+            lib.dvlp_dev_gemm_ablate(abl)
 
             def run():
                 rc = lib.dvlp_gemm(1, 0, 0, M, N, K, P(A), K, P(B), K, P(C), N, P(b_), P(r_), N if r_ is not None else 0, P(a_),
@@ -46,6 +46,6 @@ for N, K in ((3072, 768), (768, 768)):
             b.record()
             torch.cuda.synchronize()
             row.append(a.elapsed_time(b) * 50)
-        lib.dvlp_gemm_ablate(0)
+        lib.dvlp_dev_gemm_ablate(0)
         fl = 2.0 * M * N * K
         print(f"N={N:5d} K={K:5d} {label:22s} full {row[0]:7.1f} us ({fl / row[0] / 1e6:6.0f} TF)   no stores {row[1]:7.1f}   K loop only {row[2]:7.1f}   stores to 256 rows {row[3]:7.1f}   plain stores {row[4]:7.1f}")

@@ -33,11 +33,11 @@ def main():
     ap.add_argument("--wide", type=int, default=1, help="0 never / 1 heuristic / 2 always use the 256x128 tile")
     ap.add_argument("--p8", type=int, default=0, help="0 never / 1 heuristic / 2 always use the 256x256 ping-pong kernel")
     a = ap.parse_args()
-    ops.call("dvlp_gemm_p8_mode", a.p8)
-    ops.call("dvlp_gemm_variant", a.variant)
-    ops.call("dvlp_gemm_splitk_target", a.splitk_target)
-    ops.call("dvlp_gemm_ablate", a.ablate)
-    ops.call("dvlp_gemm_wide_mode", a.wide)
+    ops.call("dvlp_dev_gemm_p8_mode", a.p8)
+    ops.call("dvlp_dev_gemm_variant", a.variant)
+    ops.call("dvlp_dev_gemm_splitk_target", a.splitk_target)
+    ops.call("dvlp_dev_gemm_ablate", a.ablate)
+    ops.call("dvlp_dev_gemm_wide_mode", a.wide)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
     M = a.tokens

@@ -63,17 +63,17 @@ for label, kind, T, N, K in CASES:
     res = []
     for p8 in (0, 2, "w"):                                   # 128 x 128, 256 x 256, 256 x 128 ("wide")
         for S in (0, 1, 2, 3, 4, 6, 8):
-            ops.call("dvlp_gemm_p8_mode", 0 if p8 == "w" else p8)
-            ops.call("dvlp_gemm_wide_mode", 2 if p8 == "w" else 0)
-            ops.call("dvlp_gemm_force_split", S)
+            ops.call("dvlp_dev_gemm_p8_mode", 0 if p8 == "w" else p8)
+            ops.call("dvlp_dev_gemm_wide_mode", 2 if p8 == "w" else 0)
+            ops.call("dvlp_dev_gemm_force_split", S)
             try:
                 t = bench(fn)
                 res.append((t, p8, S))
             except Exception as e:  # noqa: BLE001
                 pass
-    ops.call("dvlp_gemm_p8_mode", 1)
-    ops.call("dvlp_gemm_wide_mode", 0)
-    ops.call("dvlp_gemm_force_split", 0)
+    ops.call("dvlp_dev_gemm_p8_mode", 1)
+    ops.call("dvlp_dev_gemm_wide_mode", 0)
+    ops.call("dvlp_dev_gemm_force_split", 0)
     t_auto = bench(fn)
     res.sort()
     best = ", ".join(f"p8={p} S={s}: {t * 1e6:.1f}us" for t, p, s in res[:4])

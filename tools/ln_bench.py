@@ -17,7 +17,7 @@ for M in (18496, 6400):
     b = torch.randn(768, device=dev, generator=g)
     outs = {}
     for mode in (0, 1, 0, 1):
-        ops.call("dvlp_layernorm_wide", mode)
+        ops.call("dvlp_dev_layernorm_wide", mode)
         for _ in range(3):
             y = ops.layernorm_fwd(x, w, b, 1e-6)
         torch.cuda.synchronize()
@@ -31,4 +31,4 @@ for M in (18496, 6400):
         outs[mode] = y
         print(f"M={M} wide={mode}: {us:6.1f} us  {2 * M * 768 * 2 / us / 1e6:5.2f} TB/s")
     print("  bit-equal y:", torch.equal(outs[0][0], outs[1][0]), " mean/rstd max diff:", (outs[0][2] - outs[1][2]).abs().max().item(), (outs[0][3] - outs[1][3]).abs().max().item())
-ops.call("dvlp_layernorm_wide", 1)
+ops.call("dvlp_dev_layernorm_wide", 1)

@@ -16,7 +16,7 @@ for B in (64, 32):
     b = torch.randn(B, 256, device=dev, generator=g).bfloat16()
     xs = torch.rand(B, B, device=dev, generator=g)
     for on in (1, 0):
-        ops.call("dvlp_loss_mfma", on)
+        ops.call("dvlp_dev_loss_mfma", on)
         ts = []
         for _ in range(20):
             torch.cuda.synchronize()
@@ -27,4 +27,4 @@ for B in (64, 32):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         print(f"B = {B}  matrix cores {'on ' if on else 'off'}: {sorted(ts)[len(ts) // 2]:7.1f} us (incl. ~20 us of output allocations and the launch)")
-ops.call("dvlp_loss_mfma", 1)
+ops.call("dvlp_dev_loss_mfma", 1)

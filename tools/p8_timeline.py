@@ -35,8 +35,8 @@ if os.environ.get("P8_ALIAS"):              # every workgroup loads tile (0, 0)'
     lib.dvlp_p8_alias.argtypes = [ctypes.c_int]
     lib.dvlp_p8_alias(1)
     print("# P8_ALIAS=1: all workgroups load the operands of tile (0, 0)")
-lib.dvlp_gemm_p8_mode(2)                    # also for grids the dispatch would give to the 128-row kernel
-lib.dvlp_gemm_p8_persistent(0)              # the stamps live in the one-tile-per-workgroup kernel
+lib.dvlp_dev_gemm_p8_mode(2)                    # also for grids the dispatch would give to the 128-row kernel
+lib.dvlp_dev_gemm_p8_persistent(0)              # the stamps live in the one-tile-per-workgroup kernel
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 shapes = [("qkv fwd (bias)", M0, 2304, 768, 0, 0, "b"), ("proj fwd (bias+res)", M0, 768, 768, 0, 0, "br"), ("fc1 fwd (gelu, aux out)", M0, 3072, 768, 0, 1, "ba"),
           ("fc2 dX (gelu', aux in)", M0, 3072, 768, 1, 2, "a"), ("fc2 fwd (bias+res) K=3072", M0, 768, 3072, 0, 0, "br"),

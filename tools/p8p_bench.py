@@ -37,12 +37,12 @@ for label, M, N, K, tb, flags, ops_ in shapes:
         C = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         aux = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16) if "a" in ops_ else None
         return C, aux
-    lib.dvlp_gemm_p8_persistent(0)
+    lib.dvlp_dev_gemm_p8_persistent(0)
     C0, aux0 = fresh()
     run(C0, aux0)
     torch.cuda.synchronize()
     assert not torch.isnan(C0.float()).any()
-    lib.dvlp_gemm_p8_persistent(1)
+    lib.dvlp_dev_gemm_p8_persistent(1)
     C1, aux1 = fresh()
     run(C1, aux1)
     torch.cuda.synchronize()
@@ -60,7 +60,7 @@ for label, M, N, K, tb, flags, ops_ in shapes:
     C, aux = fresh()
     for r in range(a.rounds):
         for mode in (0, 1):
-            lib.dvlp_gemm_p8_persistent(mode)
+            lib.dvlp_dev_gemm_p8_persistent(mode)
             for _ in range(2):
                 run(C, aux)
             torch.cuda.synchronize()
@@ -74,4 +74,4 @@ for label, M, N, K, tb, flags, ops_ in shapes:
     fl = 2.0 * M * N * K
     med = {m: sorted(t)[len(t) // 2] for m, t in times.items()}
     print(f"    one tile / WG {med[0]:7.1f} us ({fl / med[0] / 1e6:5.0f} TF)   persistent {med[1]:7.1f} us ({fl / med[1] / 1e6:5.0f} TF)   {med[0] / med[1]:.3f}x")
-lib.dvlp_gemm_p8_persistent(0)
+lib.dvlp_dev_gemm_p8_persistent(0)

@@ -29,8 +29,8 @@ for label, N, K, tb, flags in shapes:
     aux = torch.randn(M, N, device=dev, generator=g).bfloat16() if flags else None
     row = []
     for name, wide, p8 in modes:
-        lib.dvlp_gemm_wide_mode(wide)
-        lib.dvlp_gemm_p8_mode(p8)
+        lib.dvlp_dev_gemm_wide_mode(wide)
+        lib.dvlp_dev_gemm_p8_mode(p8)
 
         def run():
             rc = lib.dvlp_gemm(1, 0, tb, M, N, K, P(A), K, P(B), N if tb else K, P(C), N, P(bias), None, 0, P(aux), N if aux is not None else 0, flags, 1.0, st)
@@ -49,5 +49,5 @@ for label, N, K, tb, flags in shapes:
         row.append(f"{name} {us:6.1f} us ({2.0 * M * N * K / us / 1e6:5.0f} TF)")
     print(f"{label:16s} N={N:5d} K={K:5d}   " + "   ".join(row))
 print("sum: " + "   ".join(f"{k} {v:.1f} us" for k, v in tot.items()))
-lib.dvlp_gemm_wide_mode(0)
-lib.dvlp_gemm_p8_mode(1)
+lib.dvlp_dev_gemm_wide_mode(0)
+lib.dvlp_dev_gemm_p8_mode(1)

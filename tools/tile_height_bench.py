@@ -35,7 +35,7 @@ for label, N, K, tb, flags, ops_ in shapes:
     times = {0: [], 1: []}
     for r in range(7):
         for mode in (0, 1):
-            lib.dvlp_gemm_p8_short_tiles(mode)
+            lib.dvlp_dev_gemm_p8_short_tiles(mode)
             for _ in range(2):
                 run()
             torch.cuda.synchronize()
@@ -52,4 +52,4 @@ for label, N, K, tb, flags, ops_ in shapes:
         tot[m] += med[m]
     print(f"{label:26s} N={N:5d} K={K:5d}   256-row tiles {med[0]:7.1f} us ({fl / med[0] / 1e6:5.0f} TF)   automatic height {med[1]:7.1f} us ({fl / med[1] / 1e6:5.0f} TF)   {med[0] / med[1]:.3f}x")
 print(f"sum over one layer's forward + dX products: {tot[0]:.1f} -> {tot[1]:.1f} us ({tot[0] / tot[1]:.3f}x)")
-lib.dvlp_gemm_p8_short_tiles(1)
+lib.dvlp_dev_gemm_p8_short_tiles(1)

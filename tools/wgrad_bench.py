@@ -18,7 +18,7 @@ ap.add_argument("--separate", action="store_true", help="four dvlp_gemm launches
 ap.add_argument("--patches", type=int, default=1, help="1 (default): 3 x 3 tile patches pinned to XCDs; 0: per-problem tile order")
 ap.add_argument("--subset", default="", help="comma list of problem indices (0 fc2, 1 fc1, 2 proj, 3 qkv)")
 a = ap.parse_args()
-ops.call("dvlp_wgrad_group_patches", a.patches)
+ops.call("dvlp_dev_wgrad_group_patches", a.patches)
 dev = "cuda"
 T = a.tokens
 g = torch.Generator(device=dev).manual_seed(0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Stage costs of the bf16 per-pair backward kernel of the local loss (MI355X): time of dvlp_xattn_bwd with the kernel cut after each
-stage (dvlp_xattn_bwd_stop); differences between rows are the stages.  python tools/xbwd_stages.py [B G W]"""
+stage (dvlp_dev_xattn_bwd_stop); differences between rows are the stages.  python tools/xbwd_stages.py [B G W]"""
 import os
 import sys
 
@@ -19,11 +19,11 @@ mc = torch.zeros(B, W, device=dev)
 mc[:, 30:] = -100.0
 dsc = torch.randn(B, B, device=dev, generator=g)
 for variant, stops in ((0, (0,)), (1, (0, 6, 5, 1, 2, 3))):
-    ops.call("dvlp_xattn_bwd_variant", variant)
+    ops.call("dvlp_dev_xattn_bwd_variant", variant)
     _, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True)          # the workspace layout depends on the variant
     keep = ws.clone()
     for stop in stops:
-        ops.call("dvlp_xattn_bwd_stop", stop)
+        ops.call("dvlp_dev_xattn_bwd_stop", stop)
         ts = []
         for rep in range(5):
             ws.copy_(keep)
@@ -35,12 +35,12 @@ for variant, stops in ((0, (0,)), (1, (0, 6, 5, 1, 2, 3))):
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b) * 1e3)
         print(f"variant {variant} stop {stop}: whole backward {sorted(ts)[len(ts) // 2]:8.1f} us")
-ops.call("dvlp_xattn_bwd_stop", 0)
-ops.call("dvlp_xattn_bwd_variant", 1)
+ops.call("dvlp_dev_xattn_bwd_stop", 0)
+ops.call("dvlp_dev_xattn_bwd_variant", 1)
 
 # forward kernel (same stops): time of dvlp_xattn_fwd with the softmax kernel cut after each stage
 for stop in (0, 6, 5, 1, 2, 7):          # 7: everything but the P1 / P2 stores of the softmax kernel
-    ops.call("dvlp_xattn_bwd_stop", stop)
+    ops.call("dvlp_dev_xattn_bwd_stop", stop)
     ts = []
     for rep in range(5):
         torch.cuda.synchronize()
@@ -51,4 +51,4 @@ for stop in (0, 6, 5, 1, 2, 7):          # 7: everything but the P1 / P2 stores 
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3)
     print(f"forward stop {stop}: whole forward {sorted(ts)[len(ts) // 2]:8.1f} us")
-ops.call("dvlp_xattn_bwd_stop", 0)
+ops.call("dvlp_dev_xattn_bwd_stop", 0)

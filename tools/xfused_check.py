@@ -31,7 +31,7 @@ def case(B, G, W, seed=0, gate=True, bwd=False):
     C, Q = t(im).bfloat16(), t(cap).bfloat16()
     res = {}
     for mode in (0, 1):
-        ops.call("dvlp_xattn_fused_mode", mode)
+        ops.call("dvlp_dev_xattn_fused_mode", mode)
         s, ws = ops.xattn_fwd(C, Q, t(m_img), t(m_cap), 20.0, gate, bwd)
         res[mode] = s.cpu().numpy()
         if bwd:
@@ -58,8 +58,8 @@ def timing(B=64, G=288, W=99, bwd=False, stops=(0,)):
     ds = torch.randn(B, B, device=dev, generator=g)
     ops.ensure_gemm_workspace(C.device)
     for mode, stop in [(0, 0)] + [(1, st) for st in stops]:
-        ops.call("dvlp_xattn_fused_mode", mode)
-        ops.call("dvlp_xfused_ablate", stop)
+        ops.call("dvlp_dev_xattn_fused_mode", mode)
+        ops.call("dvlp_dev_xfused_ablate", stop)
 
         def step():
             s, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, True, bwd)
@@ -75,7 +75,7 @@ def timing(B=64, G=288, W=99, bwd=False, stops=(0,)):
         b.record()
         torch.cuda.synchronize()
         print(f"mode {mode} stop {stop} bwd={bwd}: {a.elapsed_time(b) / 5:.3f} ms")
-    ops.call("dvlp_xfused_ablate", 0)
+    ops.call("dvlp_dev_xfused_ablate", 0)
 
 
 if __name__ == "__main__":

@@ -36,8 +36,8 @@ def med(fn, reps=7):
 
 res = {}
 for variant in ((ONLY,) if ONLY is not None else (0, 1, 2)):                 # 0 generic kernels, 1 bf16 kernels with the weighted contexts materialised, 2 bf16 kernels + Gram form
-    ops.call("dvlp_xattn_bwd_variant", int(variant > 0))
-    ops.call("dvlp_xattn_gram", int(variant == 2))
+    ops.call("dvlp_dev_xattn_bwd_variant", int(variant > 0))
+    ops.call("dvlp_dev_xattn_gram", int(variant == 2))
     sc, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True)
     keep = ws.clone()
     tf = med(lambda: ops.xattn_fwd(C, Q, mi, mc, 20.0, True, True))
@@ -50,8 +50,8 @@ for variant in ((ONLY,) if ONLY is not None else (0, 1, 2)):                 # 0
     dC, dQ = bwd()
     res[variant] = (sc.clone(), dC.float().clone(), dQ.float().clone())
     print(f"variant {variant}: forward {tf:8.1f} us   backward {tb:8.1f} us")
-ops.call("dvlp_xattn_bwd_variant", 1)
-ops.call("dvlp_xattn_gram", 1)
+ops.call("dvlp_dev_xattn_bwd_variant", 1)
+ops.call("dvlp_dev_xattn_gram", 1)
 for k, name in enumerate(("scores", "dC", "dQ") if ONLY is None else ()):
     d = (res[1][k] - res[0][k]).abs().max().item()
     d2 = (res[2][k] - res[0][k]).abs().max().item()
