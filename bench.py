@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FILES = ("r3_final_gemm_hbm_traffic_pmc.json", "r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
+TRAFFIC_FILES = ("r4_final_gemm_hbm_traffic_pmc.json", "r3_final_gemm_hbm_traffic_pmc.json", "r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
 
 
 def csrc_sha():
@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
                          "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
+    ap.add_argument("--rccl-channels", type=int, default=0, help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS); 0 = RCCL's default")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1, graph mode: dtype of the gradient buckets on the links (bf16 = half the bytes; moments and master weights stay fp32)")
     ap.add_argument("--gather-negatives", action="store_true",
@@ -228,6 +229,11 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.rccl_channels > 0:
+        # RCCL beside CU-owning GEMMs: a channel is a workgroup that keeps a CU for the length of a collective; the cap is an
+        # experiment knob for the first multi-GPU run (default: RCCL's own choice)
+        os.environ["NCCL_MAX_NCHANNELS"] = str(a.rccl_channels)
+        os.environ["NCCL_MIN_NCHANNELS"] = str(min(4, a.rccl_channels))
     force_dist = world == 1 and os.environ.get("DVLP_FORCE_DIST") is not None and "MASTER_ADDR" in os.environ   # developer switch:
     if world > 1 or force_dist:                                                                              # RCCL path on one GPU
         if one_gpu:

@@ -24,9 +24,10 @@ def one(pattern):
 
 
 import subprocess
+TRAFFIC_ONLY = os.environ.get("DVLP_TRAFFIC_ONLY") is not None      # on the GPU box, between the PMC passes and the bench line (tools/profile_round.sh)
 try:
-    GIT_HEAD = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-    if subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "demovlp_amd/csrc"], capture_output=True, text=True).stdout.strip():
+    GIT_HEAD = os.environ.get("DVLP_GIT_HEAD") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    if not os.environ.get("DVLP_GIT_HEAD") and subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "demovlp_amd/csrc"], capture_output=True, text=True).stdout.strip():
         GIT_HEAD = (GIT_HEAD or "?") + "+uncommitted-csrc"
 except Exception:
     GIT_HEAD = None
@@ -35,14 +36,16 @@ try:
 except Exception:
     CSRC_SHA = None
 PROV = {"git_head": GIT_HEAD, "csrc_sha": CSRC_SHA}
-line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
-open(os.path.join(P, tag + "_bench.json"), "w").write(line)
-st = one("trace/**/*kernel_stats.csv")
-if st:
-    shutil.copy(st, os.path.join(P, tag + "_bench_kernel_stats.csv"))
-tl = [l for l in open(os.path.join(SRC, "trace_bench.json")) if l.startswith("{")]
-if tl:
-    open(os.path.join(P, tag + "_bench_under_rocprof.json"), "w").write(tl[-1])
+line = ""
+if not TRAFFIC_ONLY:
+    line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
+    open(os.path.join(P, tag + "_bench.json"), "w").write(line)
+    st = one("trace/**/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(P, tag + "_bench_kernel_stats.csv"))
+    tl = [l for l in open(os.path.join(SRC, "trace_bench.json")) if l.startswith("{")]
+    if tl:
+        open(os.path.join(P, tag + "_bench_under_rocprof.json"), "w").write(tl[-1])
 
 
 def family(name):
@@ -76,6 +79,8 @@ if fc and wc:
            "gemm_family_traffic_bytes_per_launch": traffic}
     json.dump(out, open(os.path.join(P, tag + "_gemm_hbm_traffic_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
+if TRAFFIC_ONLY:
+    sys.exit(0)
 # MFMA-busy, LDS bank conflicts and parked-wave share per kernel family (third PMC pass)
 mc = one("mfma/**/*counter_collection.csv")
 if mc:

@@ -9,10 +9,16 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # which kernels these counters belong to (bench.py reports `traffic` only for a tree whose csrc hashes to the same value)
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc_sha())" > $O/csrc_sha.txt
-timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err
+# the PMC passes FIRST, their summary written into profiles/ on this box, THEN the bench line: its roofline.traffic then names counters that were
+# taken on exactly these kernels in this very run (round 3's set had a bench line from before its PMC passes: traffic null).
+# usage: tools/profile_round.sh <tag> [git head]   (the GPU box has no .git: the caller passes the revision)
+TAG=${1:-r4_final}
+export DVLP_GIT_HEAD=${2:-}
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/write.err
+(cd $R && DVLP_TRAFFIC_ONLY=1 python3 tools/make_profiles.py $TAG > $O/traffic_summary.txt 2>&1)
+timeout 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --no-cpu-baseline > $O/trace_bench.json 2> $O/trace.err
 # MFMA-busy / LDS-bank-conflict / wait counters of the same command (third PMC pass; SQ + GRBM slots only)
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline --no-object-tower > /dev/null 2> $O/mfma.err
 # K1 alone and the local-loss kernels alone
