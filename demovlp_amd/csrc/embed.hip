@@ -391,6 +391,29 @@ extern "C" int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, con
     return dvlp_launch_status();
 }
 
+// The caption-side inputs of GlobalLocalLoss from the attention mask, one launch (trainer/trainer_dist.py:152-159): text_length[b] = sum_w att[b][w]
+// (int64, as torch.sum gives) and text_mask[b][w - 1] = (att[b][w] - 1) * 100 for w >= 1 (fp32) -- the stock form is a reduce, a slice copy, a
+// subtraction and a multiplication: four launches inside every captured step.  One wave per caption.
+__global__ __launch_bounds__(256) void text_mask_len_kernel(int64_t B, int L, const int64_t* __restrict__ att, int64_t* __restrict__ len, float* __restrict__ mask) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float cnt = 0.f;
+    for (int w = lane; w < L; w += 64) {
+        const float a = (float)att[b * L + w];
+        cnt += a;
+        if (w >= 1) mask[b * (L - 1) + w - 1] = (a - 1.0f) * 100.0f;
+    }
+    cnt = wave_sum(cnt);                                         // small integers: exact in fp32
+    if (lane == 0) len[b] = (int64_t)cnt;
+}
+extern "C" int dvlp_text_mask_len(int64_t B, int64_t L, const int64_t* att, int64_t* text_length, float* text_mask, void* stream) {
+    dvlp_clear_status();
+    if (B <= 0 || L < 2 || L > (1 << 20)) return DVLP_ERR_SHAPE;
+    hipLaunchKernelGGL(text_mask_len_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, B, (int)L, att, text_length, text_mask);
+    return dvlp_launch_status();
+}
+
 extern "C" int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
     dvlp_clear_status();
     if (n <= 0) return DVLP_ERR_SHAPE;

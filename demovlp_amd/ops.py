@@ -527,6 +527,16 @@ def text_embed_bwd(ids, de, vocab):
     return dword
 
 
+def text_mask_len(att):
+    """(text_length int64 [B], text_mask fp32 [B, L - 1]) = (att.sum(1), (att[:, 1:] - 1.0) * 100.0) in one launch (att: int64 [B, L] on the device)."""
+    B, L = att.shape
+    att = att.contiguous()
+    length = torch.empty(B, device=att.device, dtype=torch.int64)
+    mask = torch.empty((B, L - 1), device=att.device, dtype=torch.float32)
+    call("dvlp_text_mask_len", B, L, p(att), p(length), p(mask), stream())
+    return length, mask
+
+
 def copy_by_kernel(dst, src):
     """dst <- src through a kernel launch rather than ``copy_`` (= hipMemcpyAsync for contiguous same-dtype tensors).  Inside a captured
     step a copy / memset becomes a memcpy / memset NODE, and those were not reliably ordered against the kernels around them when a replay

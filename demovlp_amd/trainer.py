@@ -428,9 +428,13 @@ def backward_first(model, loss_fn, data, gather_negatives=None):
     """trainer/trainer_dist.py:148-165: forward, masks, sim_matrix, GlobalLocalLoss and ``loss.backward()``.  When the object tower
     carries a ``grad_cut`` the backward stops at that block's input (text tower, heads and the upper object blocks are done; their
     gradients are final when this returns) and ``backward_second`` finishes it.  Returns the three detached losses."""
-    text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+    att = data["text"]["attention_mask"]
     out = model(data)
-    text_mask = (data["text"]["attention_mask"][:, 1:] - 1.0) * 100.0      # (:156-159; the subtraction already yields a contiguous tensor)
+    if att.is_cuda and att.dtype == torch.int64 and att.dim() == 2 and att.shape[1] >= 2:
+        text_length, text_mask = ops.text_mask_len(att)          # one launch instead of a reduce, a slice copy, a subtraction and a multiplication
+    else:
+        text_length = torch.sum(att, dim=1)
+        text_mask = (att[:, 1:] - 1.0) * 100.0                   # (:156-159; the subtraction already yields a contiguous tensor)
     if gather_negatives is not None:
         out, text_length, text_mask = gather_embeddings(out, text_length, text_mask, gather_negatives)
     global_sim = sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"])

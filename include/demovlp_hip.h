@@ -187,6 +187,9 @@ int dvlp_text_embed_fwd(int dtype, int64_t B, int64_t L, const int64_t* ids, con
                         void* stream);
 int dvlp_text_embed_bwd(int dtype, int64_t M, const int64_t* ids, const void* de, float* dword, void* stream);
 int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream);
+/* the loss' caption-side inputs from the attention mask in one launch (trainer/trainer_dist.py:152-159): text_length[b] = sum_w att[b][w] (int64)
+   and text_mask[b][w - 1] = (att[b][w] - 1) * 100, w = 1 .. L - 1 (fp32 [B, L - 1]); att int64 [B, L] */
+int dvlp_text_mask_len(int64_t B, int64_t L, const int64_t* att, int64_t* text_length, float* text_mask, void* stream);
 
 /* ---- dropout of the text tower: the reference keeps DistilBERT in train mode (model/model.py:29-30), so HuggingFace's three
  *      dropouts (embeddings, attention probabilities, feed-forward output; p = 0.1) are part of every training step.  Masks are

@@ -128,3 +128,15 @@ def test_bf16_trains_like_fp32_at_the_benchmark_size(lr, steps, rel_tol, drift_t
     assert r["max_rel"] < rel_tol and r["drift"] < drift_tol and r["cos"] > cos_min
     assert np.isfinite(r["l16"]).all() and r["l16"][-1, 0] < r["l16"][0, 0]                # it descends, as the fp32 run does
     assert abs((r["l16"][0, 0] - r["l16"][-1, 0]) - (r["l32"][0, 0] - r["l32"][-1, 0])) < 0.1 * abs(r["l32"][0, 0] - r["l32"][-1, 0]) + 2 * r["max_dev"]
+
+
+def test_text_mask_len_kernel_equals_the_stock_ops():
+    """dvlp_text_mask_len (one launch inside the captured step) against the reference's own expressions, trainer/trainer_dist.py:152-159: exact."""
+    from demovlp_amd import ops
+    for B, L in ((64, 100), (3, 2), (5, 37), (1, 300)):
+        ids, att = syn.caption_batch(B, text_len=max(L, 34))
+        att = torch.from_numpy(att[:, :L].copy()).to(DEV)
+        att[:, 0] = 1
+        length, mask = ops.text_mask_len(att)
+        assert length.dtype == torch.int64 and torch.equal(length, torch.sum(att, dim=1))
+        assert mask.dtype == torch.float32 and torch.equal(mask, (att[:, 1:] - 1.0) * 100.0)
