@@ -87,16 +87,19 @@ def _graph_dp_worker(rank, world, port, q, cut):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        grad_dtype = "float32"
         if isinstance(cut, tuple) and cut and cut[-1] == "side-stream":
             # weight gradients on the gradient side stream: every piece must join it before its ranges are exchanged
             from demovlp_amd import functional as Fn
             Fn.OVERLAP_WGRAD = 2
             cut = cut[:-1]
+        if isinstance(cut, tuple) and cut and cut[-1] == "bf16-buckets":
+            grad_dtype, cut = "bfloat16", cut[:-1]              # every bucket crosses as bf16 (cast kernel, bf16 sum, cast back into the fp32 arena)
         F, R, B = 8, 36, 2
         model = build(F, R)
         arena = ParamArena(model)
         opt = FusedAdamW(arena, lr=1e-3)
-        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0)
+        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0, grad_dtype=grad_dtype)
         losses = []
         for s in range(NSTEP):
             out = stepper(to_dev(*_np_batch(F, R, B, rank, s)))
@@ -141,8 +144,8 @@ def _hand_averaged_reference():
     return _HAND_REF[0]
 
 
-@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), pytest.param(6, marks=pytest.mark.slow), None],
-                         ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "two-graphs-cut6", "one-graph"])
+@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), (8, 4, "bf16-buckets"), pytest.param(6, marks=pytest.mark.slow), None],
+                         ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "three-graphs-bf16-buckets", "two-graphs-cut6", "one-graph"])
 def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     """Two processes on cuda:0, each with its own batch per step, five steps through GraphedTrainStep (two of them replays of the
     captured graphs with the bucketed gradient exchange between / behind them and the fused optimizer applied bucket by bucket on
@@ -150,7 +153,8 @@ def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     1e-5 of max|p| -- to one process that runs both batches, sums the gradients itself and steps with grad_scale 1/2."""
     res = _spawn(_graph_dp_worker, (cut,))
     (_, l0, p0, s0, info), (_, l1, p1, s1, _) = res
-    if isinstance(cut, tuple) and cut[-1] == "side-stream":
+    half = isinstance(cut, tuple) and cut[-1] == "bf16-buckets"
+    if isinstance(cut, tuple) and cut[-1] in ("side-stream", "bf16-buckets"):
         cut = cut[:-1]
     assert info["captured"] and info["steps"] == NSTEP
     assert info["graph2"] == (cut is not None) and (info["early"] >= 2 if cut is not None else info["early"] == 0)
@@ -159,10 +163,12 @@ def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     ref_losses, pref = _hand_averaged_reference()
     for s in range(NSTEP):
         for r, l in ((0, l0), (1, l1)):
-            assert abs(l[s] - ref_losses[s][r]) < 1e-5 * max(1.0, abs(l[s])), (s, r, l[s], ref_losses[s][r])
+            assert abs(l[s] - ref_losses[s][r]) < (5e-3 if half else 1e-5) * max(1.0, abs(l[s])), (s, r, l[s], ref_losses[s][r])
     dev = np.abs(p0 - pref).max() / max(1.0, np.abs(pref).max())
     print("\nparameters after %d data-parallel graph steps vs hand-averaged reference: max rel dev %.3g" % (NSTEP, dev))
-    assert dev <= 1e-5
+    # bf16 buckets: the summed gradients carry three bf16 roundings (2^-9 each); Adam's m / sqrt(v) turns that into <= a few per cent of lr = 1e-3
+    # per step on some elements -- observed 1.6e-3 after five steps; the fp32 exchange is exact to the hand-averaged reference
+    assert dev <= (5e-3 if half else 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -845,7 +851,7 @@ def _graph_dp_bf16_worker(rank, world, port, q, cut):
         model = build(F, R, "bfloat16")
         arena = ParamArena(model, bf16_shadow=True)
         opt = FusedAdamW(arena, lr=1e-4)
-        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0)
+        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0, grad_dtype=grad_dtype)
         losses = []
         for s in range(7):
             out = stepper(to_dev(*_np_batch(F, R, B, rank, s)))
