@@ -366,7 +366,11 @@ def main():
         xt = stepper.exchange_times()
         stepper.time_exchange = False
         npieces = len(stepper.piece_runs)
-        exchange = [{"piece": k, "mb": round(xt[k][1] / 2 ** 20, 1), "ms": round(sum(t for t, _ in xt[k::npieces]) / max(1, len(xt[k::npieces])), 3)} for k in range(npieces)]
+        exchange = []
+        for k in range(npieces):                              # grouped by the piece index each entry carries: a piece with no ranges records none
+            mine = [(t, n) for t, n, piece in xt if piece == k]
+            exchange.append({"piece": k, "mb": round(mine[0][1] / 2 ** 20, 1) if mine else 0.0,
+                             "ms": round(sum(t for t, _ in mine) / len(mine), 3) if mine else 0.0})
     obj_s, obj_mode = None, None
     if not a.no_object_tower:
         obj_s, obj_mode = time_object_tower(model, data, max(3, min(a.steps, 10)), sync, graph=use_graph)

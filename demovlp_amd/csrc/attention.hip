@@ -1471,6 +1471,9 @@ extern "C" int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int
                                   const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk,
                                   void* dv, int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out,
                                   const float* cls_stats, void* stream) {
-    return dvlp_attention_bwd_ex(dtype, mode, B, N, H, F, R, q, k, v, ld, addmask, dout, ldo, dq, dk, dv, ldd, workspace, scale, fwd_out, ld_fwd_out, cls_stats,
+    // the plain forward never folds the CLS query (it cannot report whether `cls_stats` were written), so statistics handed to the plain
+    // backward cannot have come from it: take the two-pass form, which recomputes them, whatever the caller passed
+    (void)fwd_out; (void)ld_fwd_out; (void)cls_stats;
+    return dvlp_attention_bwd_ex(dtype, mode, B, N, H, F, R, q, k, v, ld, addmask, dout, ldo, dq, dk, dv, ldd, workspace, scale, nullptr, 0, nullptr,
                                  nullptr, stream);
 }

@@ -655,7 +655,7 @@ class GraphedTrainStep:
             if not self.collective:
                 self.opt.launch(grad_scale=1.0)
 
-    def _exchange_and_update(self, runs):
+    def _exchange_and_update(self, runs, piece=0):
         """All-reduce the given arena ranges of the gradient buffer (sum) and update the parameters of each reduced piece: collectives
         queue on the communication stream behind what the current stream holds so far, each fused-AdamW range launch waits (on the
         optimizer stream) for just its own piece."""
@@ -695,7 +695,7 @@ class GraphedTrainStep:
                 for h in handles:
                     h.wait()
                 ev[1].record()
-                self._xev.append(ev)
+                self._xev.append(ev + (piece,))
         with torch.cuda.stream(self._optst):
             for h, (lo, hi) in zip(handles, pieces):
                 h.wait()                                      # this stream waits for that collective only
@@ -704,10 +704,11 @@ class GraphedTrainStep:
                 ops.adamw_range_dev(a.flat_p, g, self.opt.m, self.opt.v, self.opt._hyper, a.flat_s, lo, hi)
 
     def exchange_times(self):
-        """[(milliseconds, bytes)] per exchanged piece since the last call, in issue order (``time_exchange=True``): the time the piece's
-        collectives occupied the communication stream -- NOT what the step waited for (all but the last piece run beside the next graph)."""
+        """[(milliseconds, bytes, piece)] per exchanged piece since the last call, in issue order (``time_exchange=True``): the time the
+        piece's collectives occupied the communication stream -- NOT what the step waited for (all but the last piece run beside the next
+        graph).  A piece with nothing to exchange records no entry: group by the piece index, not by position."""
         torch.cuda.synchronize()
-        out = [(a.elapsed_time(b), n) for a, b, n in self._xev]
+        out = [(a.elapsed_time(b), n, k) for a, b, n, k in self._xev]
         self._xev = []
         return out
 
@@ -742,11 +743,17 @@ class GraphedTrainStep:
                 else:
                     self._piece(k, data)
                 if self.collective:
-                    self._exchange_and_update(self.piece_runs[k])
+                    self._exchange_and_update(self.piece_runs[k], piece=k)
         except BaseException:
             # _begin_updates() advanced the device step counter and earlier pieces may already be updated (their moments too): the
             # host count did not move, so have the next _sync_hyper() rewrite the device counter from it
             self.opt._hyper_step = -1
+            if self._optst is not None:
+                # ... but only once the aborted step's update launches have drained: they still read the hyper-parameter block on the
+                # optimizer stream (behind collectives on the communication stream), and the rewrite happens on the current one
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._comm)
+                cur.wait_stream(self._optst)
             raise
         if self.collective:
             if self.opt.arena.flat_g.is_cuda:

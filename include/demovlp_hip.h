@@ -131,7 +131,9 @@ int dvlp_colsum(int dtype, int64_t M, int64_t N, const void* x, int64_t ld, int6
 /* `workspace` (B*H*F*66 floats) and `cls_stats` (B*H*4 floats), both optional (mode 0, bf16): the CLS query -- the one query that
    attends to every key of the clip (object_transformer.py:162-167) -- is folded into the per-frame waves, merged flash-style by a
    64-thread launch, and its softmax statistics stay in `cls_stats` for dvlp_attention_bwd (`fwd_out` = this call's `out`), which
-   then needs no statistics pass.  Backward workspace (mode 0): B*H*(F*192 + 4) floats. */
+   then needs no statistics pass.  Backward workspace (mode 0): B*H*(F*192 + 4) floats.
+   The two PLAIN calls below never fold: dvlp_attention_fwd leaves `cls_stats` untouched and dvlp_attention_bwd ignores `fwd_out` /
+   `cls_stats` (it recomputes the statistics) -- pairing them is always safe; the fold is a contract of the `_ex` pair (ext->folded). */
 int dvlp_attention_fwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int64_t F, int64_t R, const void* q, const void* k,
                        const void* v, int64_t ld, const float* addmask, void* out, int64_t ldo, float scale, float* workspace,
                        float* cls_stats, void* stream);

@@ -841,7 +841,7 @@ def test_replays_with_a_host_synchronisation_between_them(dtype):
         assert torch.equal(pf, finals[0][1])
 
 
-def _graph_dp_bf16_worker(rank, world, port, q, cut):
+def _graph_dp_bf16_worker(rank, world, port, q, cut, grad_dtype="float32"):
     import traceback
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -864,12 +864,14 @@ def _graph_dp_bf16_worker(rank, world, port, q, cut):
         dist.destroy_process_group()
 
 
-def test_two_rank_bf16_graphed_step_with_host_sync_is_in_lock_step_and_reproducible():
+@pytest.mark.parametrize("grad_dtype", ["float32", pytest.param("bfloat16", marks=pytest.mark.slow)])
+def test_two_rank_bf16_graphed_step_with_host_sync_is_in_lock_step_and_reproducible(grad_dtype):
     """The data-parallel graph path in bf16 (three graphs, bucketed exchange, optimizer per bucket) with the loss read on the host every
-    step: the two ranks stay bit-equal, every loss is finite, and a second launch of the same job reproduces the first bit for bit."""
+    step: the two ranks stay bit-equal, every loss is finite, and a second launch of the same job reproduces the first bit for bit.
+    Gradient buckets cross as fp32 in the default run and as bf16 (cast kernel, bf16 sum, cast back) in the --runslow variant."""
     runs = []
     for _ in range(2):
-        (_, l0, p0, s0), (_, l1, p1, s1) = _spawn(_graph_dp_bf16_worker, ((8, 4),))
+        (_, l0, p0, s0), (_, l1, p1, s1) = _spawn(_graph_dp_bf16_worker, ((8, 4), grad_dtype))
         assert np.array_equal(p0, p1) and s0 == s1
         assert np.isfinite(l0).all() and np.isfinite(l1).all() and np.isfinite(p0).all()
         runs.append((l0, l1, p0, s0))

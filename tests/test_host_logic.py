@@ -430,3 +430,20 @@ def test_bf16_gradient_buckets_gloo_world2():
     assert np.abs(f0 - want).max() <= 1e-9
     rel = np.abs(h0 - want).max() / np.abs(want).max()
     assert 0 < rel < 2 ** -7, rel                                                  # bf16 inputs + a bf16 sum: three roundings of 2^-9
+
+
+def test_no_undefined_names_anywhere_in_the_tree():
+    """Round 4's GPU suite went red on `grad_dtype=grad_dtype` inside a worker that has no such name -- a NameError only the GPU box could
+    raise.  Python's own symbol tables find that class of slip in a second: every name a function loads must be local, enclosing,
+    module-level, imported or a builtin, in tests/, the package, tools/, oracle/, bench.py and __graft_entry__.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import undefined_names as un
+    # the scanner must see the very slip it was written for
+    slip = ("def outer():\n    grad_dtype = 'float32'\n    return grad_dtype\n\n"
+            "def worker(rank):\n    return dict(rank=rank, grad_dtype=grad_dtype)\n")
+    assert un.scan_source(slip, "slip.py") == [("slip.py", "worker", "grad_dtype")]
+    assert un.scan_source("import os\nX = 1\ndef f(a):\n    global Y\n    Y = a\n    return [os.sep, X, Y, len(a)] + [b for b in a]\n") == []
+    files = list(un.tree_files())
+    assert len(files) > 40 and any(f.endswith("test_gpu_round3.py") for f in files)
+    bad = [b for f in files for b in un.scan(f)]
+    assert not bad, "\n".join("%s: %s: undefined name %r" % b for b in bad)
