@@ -66,6 +66,8 @@ __device__ __forceinline__ void keep4(const uint8_t* p, float scale, float (&m)[
     for (int t = 0; t < 4; ++t) m[t] = ((kb >> (8 * t)) & 1u) ? scale : 0.f;
 }
 static int g_attn_abl = 0;
+static int g_attn_lean = 1;        // space-mode bf16, CLS folded: 1 = the round-5 kernels (buffer addressing, swapped output products), 0 = rounds 3-4 (A/B, tests)
+extern "C" int dvlp_dev_attention_lean(int on) { g_attn_lean = on; return DVLP_OK; }
 static int g_attn_merged = 1;      // space-mode bf16 backward: 1 = one-pass form, 0 = the three-launch form (A/B, tests)
 extern "C" int dvlp_dev_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
 extern "C" int dvlp_dev_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
@@ -546,117 +548,279 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     return r;
 }
 
-// (space mode, NKT <= 3: four waves per SIMD -- 116 registers without spilling against 139 at the compiler's own choice of three; the kernel is
-//  one load -> compute -> store pass per wave, so resident waves are what hides its memory latency.  The 7 / 8-tile text form would spill.)
-template <int NQT, int NKT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NKT <= 3 ? 4 : 2))) void mattn_fwd_kernel(AttnArgs a, int items, int qgroups) {
+// (space mode, NKT <= 3: four waves per SIMD; the 7 / 8-tile text form would spill there.)  The key mask is one 4-byte load per lane
+// (key = lane) fanned out by ds_bpermute instead of twelve loads per lane (round 5: 116 -> 112 registers, 31.8 -> 30 us at the bench shape).
+template <int NQT, int NKT, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void mattn_fwd_kernel(AttnArgs a, int items, int qgroups) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     constexpr int NKTP = (NKT + 1) & ~1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
     const int item = blockIdx.x * 4 + wid;
     if (item >= items) return;                                   // wave-uniform: EXEC stays full for the tr-reads
+    const bool fold = a.mode == 0 && a.cls_o != nullptr;        // wave-uniform: the CLS query is query row R of this frame's tile
+    const int cq = a.R >> 4, cc = a.R & 15;                      // its tile and column in the S^T layout
+    const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; bf16* out = (bf16*)a.out;
+    bf16* Vs = (bf16*)smraw + wid * (NKTP * 16 * VLD);
+    bf16x8 qf[NQT][2], vfr[NKT][2];
+    float mlane = 0.f;                                           // additive mask of key `lane` of the item's segment (-inf: no such key)
     Seg sg{a.mode, a.R, a.N, 0, 0};
     int h, b;
     if (a.mode == 0) { sg.f = item % a.F; h = (item / a.F) % a.H; b = item / (a.F * a.H); }
     else { sg.qbase = (item % qgroups) * 16 * NQT; h = (item / qgroups) % a.H; b = item / (qgroups * a.H); }
-    const bool fold = a.mode == 0 && a.cls_o != nullptr;        // wave-uniform: the CLS query is query row R of this frame's tile
-    const int cq = a.R >> 4, cc = a.R & 15;                      // its tile and column in the S^T layout
-    const Seg sge = sg;                                          // rows emitted to `out`: the frame's regions only
+    Seg sge = sg;                                                // rows emitted to `out`: the frame's regions only
     sg.cls_q = fold ? 1 : 0;
     const int64_t brow0 = (int64_t)b * a.N;
-    const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; bf16* out = (bf16*)a.out;
-    bf16* Vs = (bf16*)smraw + wid * (NKTP * 16 * VLD);
-    bf16x8 qf[NQT][2], vfr[NKT][2];
     load_row_frags<NQT>(qf, q, brow0, a.ld, h, sg, false, lane);
     load_row_frags<NKT>(vfr, v, brow0, a.ld, h, sg, true, lane);      // one load phase: V goes to LDS from registers below
-    f32x4 st[NKT][NQT];
+    if constexpr (NKT <= 4) { const int tok = sg.tok_k(lane); mlane = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
+    {
+        f32x4 st[NKT][NQT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        int tok = sg.tok_k(16 * kt + c);
-        tok = tok < 0 ? 0 : tok;
-        const bf16* p = k + (brow0 + tok) * a.ld + h * HD + 8 * g;
-        const bf16x8 k0 = *(const bf16x8*)p, k1 = *(const bf16x8*)(p + 32);
+        for (int kt = 0; kt < NKT; ++kt) {
+            int tokk = sg.tok_k(16 * kt + c);                    // K straight from memory, a tile at a time
+            tokk = tokk < 0 ? 0 : tokk;
+            const bf16* pk = k + (brow0 + tokk) * a.ld + h * HD + 8 * g;
+            const bf16x8 k0 = *(const bf16x8*)pk, k1 = *(const bf16x8*)(pk + 32);
 #pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qt][0], acc, 0, 0, 0);
-            st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qt][1], acc, 0, 0, 0);
+            for (int qt = 0; qt < NQT; ++qt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qt][0], acc, 0, 0, 0);
+                st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qt][1], acc, 0, 0, 0);
+            }
         }
-    }
-    put_row_frags<NKT, NKTP>(Vs, vfr, lane);
-    float mk[NKT][4];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int tok = sg.tok_k(16 * kt + 4 * g + r); mk[kt][r] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) {
-        float m = -INFINITY;
+        put_row_frags<NKT, NKTP>(Vs, vfr, lane);
+        float mkc[NKT][4];                                       // key 16 kt + 4 g + r: one 4-byte load per lane fanned out (twelve loads per lane before)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r];
-                // CLS query x CLS key belongs to frame 0's partial only
-                if (kt == 0 && r == 0 && fold && qt == cq && c == cc && g == 0 && sg.f != 0) st[kt][qt][r] = -INFINITY;
-                m = fmaxf(m, st[kt][qt][r]);
+                if constexpr (NKT <= 4) mkc[kt][r] = __shfl(mlane, 16 * kt + 4 * g + r, 64);
+                else { const int tok = sg.tok_k(16 * kt + 4 * g + r); mkc[kt][r] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
             }
-        m = col4_max(m);
-        float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int qt = 0; qt < NQT; ++qt) {
+            float m = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
-        sum = col4_sum(sum);
-        if (fold && qt == cq && c == cc && g == 0) { a.cls_st[2 * (int64_t)item] = m; a.cls_st[2 * (int64_t)item + 1] = sum; }
-        const float inv = 1.f / sum;
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+                for (int r = 0; r < 4; ++r) {
+                    st[kt][qt][r] = st[kt][qt][r] * a.scale + mkc[kt][r];
+                    // CLS query x CLS key belongs to frame 0's partial only
+                    if (kt == 0 && r == 0 && fold && qt == cq && c == cc && g == 0 && sg.f != 0) st[kt][qt][r] = -INFINITY;
+                    m = fmaxf(m, st[kt][qt][r]);
+                }
+            m = col4_max(m);
+            float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st[kt][qt][r] *= inv;
-        if (a.keep && a.mode == 1) {                                 // weights = dropout(softmax(scores)) before the context product
-            int qi = sg.qbase + 16 * qt + c;
-            qi = qi < a.N ? qi : a.N - 1;
-            const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const uint32_t kw = *(const uint32_t*)(kr + 16 * kt + 4 * g);
+                for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
+            sum = col4_sum(sum);
+            if (fold && qt == cq && c == cc && g == 0) { a.cls_st[2 * (int64_t)item] = m; a.cls_st[2 * (int64_t)item + 1] = sum; }
+            const float inv = 1.f / sum;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[kt][qt][r] *= ((kw >> (8 * r)) & 1u) ? a.kscale : 0.f;
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][qt][r] *= inv;
+            if (a.keep && a.mode == 1) {                                 // weights = dropout(softmax(scores)) before the context product
+                int qi = sg.qbase + 16 * qt + c;
+                qi = qi < a.N ? qi : a.N - 1;
+                const uint8_t* kr = a.keep + (((int64_t)b * a.H + h) * a.Ns + qi) * a.Ns;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const uint32_t kw = *(const uint32_t*)(kr + 16 * kt + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[kt][qt][r] *= ((kw >> (8 * r)) & 1u) ? a.kscale : 0.f;
+                }
             }
         }
-    }
-    f32x4 o[NQT][4];
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NKTP / 2; ++s) {
-        const int kt0 = 2 * s, kt1 = 2 * s + 1;
-        bf16x8 pa[NQT];
-#pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) pa[qt] = pack8(st[kt0][qt], kt1 < NKT ? st[kt1 < NKT ? kt1 : kt0][qt] : zero4);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 vb = tr_pair(lds_addr(&Vs[(16 * kt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
-                                      lds_addr(&Vs[(16 * kt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
-#pragma unroll
-            for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[qt], vb, o[qt][dt], 0, 0, 0);
-        }
-    }
-    if (fold) {          // the CLS row's partial (normalised over this frame's keys) stays fp32: merged by attn_fwd_cls_combine_kernel
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 pa[NKTP / 2][NQT];                                // P as the context product's A operand (bf16): half the registers of `st`
+        f32x4 o[NQT][4];
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * qt + 4 * g + r == a.R) {
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = zero4;
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) a.cls_o[(int64_t)item * HD + 16 * dt + c] = o[qt][dt][r];
-                }
+        for (int s = 0; s < NKTP / 2; ++s) {
+            const int kt0 = 2 * s, kt1 = 2 * s + 1;
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) pa[s][qt] = pack8(st[kt0][qt], kt1 < NKT ? st[kt1 < NKT ? kt1 : kt0][qt] : zero4);     // (a k-step at a time: the text form has no room for all of it)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vb = tr_pair(lds_addr(&Vs[(16 * kt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                          lds_addr(&Vs[(16 * kt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[s][qt], vb, o[qt][dt], 0, 0, 0);
+            }
+        }
+        if (fold) {          // the CLS row's partial (normalised over this frame's keys) stays fp32: merged by attn_fwd_cls_combine_kernel
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * qt + 4 * g + r == a.R) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) a.cls_o[(int64_t)item * HD + 16 * dt + c] = o[qt][dt][r];
+                    }
+        }
+        emit_rows<NQT>(Vs, o, 1.f, out, brow0, a.ldo, h, sge, false, lane);
     }
-    emit_rows<NQT>(Vs, o, 1.f, out, brow0, a.ldo, h, sge, false, lane);
+}
+
+// ==================================================================================================================
+// Round 5 -- space attention, bf16, the "lean" forward.  Round 4 read this kernel as latency-bound at 3.6 TB/s (one load -> compute -> store
+// pass per wave).  Two experiments say otherwise (profiles/r5_attention_experiments.txt): a persistent form with the NEXT item's operands in
+// flight through the whole current item is no faster (27.5-31 us against 26-30), at two waves per SIMD as at four, with the round-4 stream
+// as with this one; and halving the instruction stream (1 719 -> 905 instructions per 37 x 37 x 64 item, 42 of them MFMAs) buys 15 %.
+// The first round of 4 096 waves asks for 75 MB at once and the memory system delivers this access shape -- 16 rows x 64 bytes per load
+// instruction, 128-byte head slices 4.6 KB apart -- at ~4.3 TB/s whatever is in flight: the kernel is memory-bound at the rate of its
+// access shape, and what the instruction diet removes is the tail behind the last round's loads.  The diet:
+//   * operands through buffer loads: one descriptor per tensor, the (batch, head) part of the address in the scalar offset, a 32-bit
+//     per-lane row offset (one multiply-add per row tile);
+//   * the context product with its operands swapped (O^T = V^T P^T): a lane then holds FOUR CONSECUTIVE CHANNELS of one query row, so the
+//     output is staged with one 8-byte LDS store per 16 x 16 tile (12 instead of 48 two-byte ones) and the CLS partial leaves as four
+//     16-byte stores under one test;
+//   * the four transposing reads of a k-step pair issued together, one wait.
+// Same arithmetic per output element as mattn_fwd_kernel (the swapped product sums the same terms in the same order).
+// ==================================================================================================================
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 buf_row16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// the B (or A) operands of four 16-channel tiles of one 32-deep k-step from a row-major LDS tile: eight transposing reads, one wait
+__device__ __forceinline__ void tr_quad(bf16x8 (&o)[4], unsigned a0, unsigned a1) {
+    bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %9 offset:32\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %9 offset:64\n\t"
+                 "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %9 offset:96\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3) : "v"(a0), "v"(a1) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    o[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+    o[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    o[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+    o[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ u32x2_t pack4(const f32x4& a) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t lo = {(bf16)a[0], (bf16)a[1]}, hi = {(bf16)a[2], (bf16)a[3]};
+    return (u32x2_t){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sattn_fwd_kernel(AttnArgs a, int items) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int NTP = (NT + 1) & ~1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wid));
+    if (item >= items) return;                                   // wave-uniform: EXEC stays full for the tr-reads
+    const int R = a.R;
+    const bool fold = a.cls_o != nullptr;                        // the CLS query is query row R of this frame's tile
+    const int cq = R >> 4, cc = R & 15;
+    const int ldb = (int)a.ld * 2, ldob = (int)a.ldo * 2;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.q), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.k), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.v), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);
+    bf16* Vs = (bf16*)smraw + wid * (NTP * 16 * VLD);
+    // one load phase: q (rows = the frame's regions, + the CLS token as row R), k / v (row 0 = the CLS token, rows 1..R the regions);
+    // rows past the end re-read token 0 (finite values; their scores are masked / their outputs not written)
+    const int f = item % a.F, h = (item / a.F) % a.H, b = item / (a.F * a.H), fR = f * R;
+    const int soff = (b * a.N * (int)a.ld + h * HD) * 2, soffo = (b * a.N * (int)a.ldo + h * HD) * 2;
+    bf16x8 qf[NT][2], kf[NT][2], vfr[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = 16 * t + c;
+        const int vq = (i < R ? 1 + fR + i : 0) * ldb + 16 * g, vk = (i >= 1 && i <= R ? fR + i : 0) * ldb + 16 * g;
+        qf[t][0] = buf_row16(rq, vq, soff); qf[t][1] = buf_row16(rq, vq + 64, soff);
+        kf[t][0] = buf_row16(rk, vk, soff); kf[t][1] = buf_row16(rk, vk + 64, soff);
+        vfr[t][0] = buf_row16(rv, vk, soff); vfr[t][1] = buf_row16(rv, vk + 64, soff);
+    }
+    const float mlane = lane <= R ? a.addmask[(int64_t)b * a.N + (lane == 0 ? 0 : fR + lane)] : -INFINITY;      // additive mask of key `lane`
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 st[NT][NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[qt][0], zero4, 0, 0, 0);
+                st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], qf[qt][1], acc, 0, 0, 0);
+            }
+        put_row_frags<NT, NTP>(Vs, vfr, lane);
+        float mk[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[kt][r] = __shfl(mlane, 16 * kt + 4 * g + r, 64);
+        bf16x8 pa[NTP / 2][NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r];
+                    // CLS query x CLS key belongs to frame 0's partial only
+                    if (kt == 0 && r == 0 && fold && qt == cq && c == cc && g == 0 && f != 0) st[kt][qt][r] = -INFINITY;
+                    m = fmaxf(m, st[kt][qt][r]);
+                }
+            m = col4_max(m);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
+            sum = col4_sum(sum);
+            if (fold && qt == cq && c == cc && g == 0) { a.cls_st[2 * (int64_t)item] = m; a.cls_st[2 * (int64_t)item + 1] = sum; }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][qt][r] *= inv;
+#pragma unroll
+            for (int s = 0; s < NTP / 2; ++s) pa[s][qt] = pack8(st[2 * s][qt], 2 * s + 1 < NT ? st[2 * s + 1 < NT ? 2 * s + 1 : 2 * s][qt] : zero4);
+        }
+        // O^T = V^T P^T: o[qt][dt][r] = O[query 16 qt + c][channel 16 dt + 4 g + r]
+        f32x4 o[NT][4];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = zero4;
+#pragma unroll
+        for (int s = 0; s < NTP / 2; ++s) {
+            bf16x8 vb[4];
+            tr_quad(vb, lds_addr(&Vs[(32 * s + 4 * g + qq) * VLD + 4 * pp]), lds_addr(&Vs[(32 * s + 16 + 4 * g + qq) * VLD + 4 * pp]));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[dt], pa[s][qt], o[qt][dt], 0, 0, 0);
+        }
+        if (fold) {          // the CLS row's partial (normalised over this frame's keys) stays fp32: merged by attn_fwd_cls_combine_kernel
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt)
+                if (qt == cq && c == cc) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        *(float4*)&a.cls_o[(int64_t)item * HD + 16 * dt + 4 * g] = make_float4(o[qt][dt][0], o[qt][dt][1], o[qt][dt][2], o[qt][dt][3]);
+                }
+        }
+        // stage the frame's rows in the tile (8-byte pieces), leave as whole 128-byte head rows
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(u32x2_t*)&Vs[(16 * qt + c) * VLD + 16 * dt + 4 * g] = pack4(o[qt][dt]);
+#pragma unroll
+        for (int it = 0; it < NT * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            if (row < R)
+                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t*)&Vs[row * VLD + ch * 8], ro, (1 + fR + row) * ldob + ch * 16, soffo, 0);
+        }
+    }
 }
 
 // CLS query, forward: merge the F per-frame partials of one (b, h) -- out = sum_f w_f o_f, w_f = l_f e^(m_f - M) / L -- and keep the
@@ -855,24 +1019,34 @@ __global__ __launch_bounds__(256) void mattn_bwd_space_kernel(AttnArgs a, int it
 //            operand, K is read with the transposing read.  Per-frame partials of the shared CLS key go to `ws` as before;
 //   launch C (attn_bwd_cls_post_kernel): sums those partials into dK / dV of the CLS key.
 // ------------------------------------------------------------------------------------------------------------------
-// (two waves per SIMD: left alone the compiler takes 328 VGPRs for NT = 3 -- one wave per SIMD, 102 us per layer.  With Q and K
-//  re-read for the second / third stage instead of held in registers it fits 244 without spilling: 80 us.  Three waves per SIMD
-//  would spill ~100 registers and take 129 us.)
+// (two waves per SIMD: left alone the compiler takes 328 VGPRs for NT = 3 -- one wave per SIMD, 102 us per layer.  Rounds 1-4 re-read Q and
+//  K from global memory for the second / third stage instead of holding them: 244 registers, 62 us, three exposed load latencies per wave.)
+// Round 5: (1) TWO LDS tiles per wave (18 KB x 8 waves fit the CU at two waves per SIMD): dO and Q are parked in them as soon as they
+// arrive, K follows when the first tile is free -- no operand is fetched twice and none is held in registers across a stage; (2) P and dS
+// are kept as the bf16 operands the three later products consume (48 registers instead of 72).  62 -> 56 us per layer at the bench shape.
 template <int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mattn_bwd_space_merged_kernel(AttnArgs a, int items, const float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
-    constexpr int NTP = (NT + 1) & ~1, TROWS = 16 * NTP;
+    constexpr int NTP = (NT + 1) & ~1, TROWS = 16 * NTP, NS = NTP / 2;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
     const int item = blockIdx.x * 4 + wid;
     if (item >= items) return;
-    Seg sg{0, a.R, a.N, item % a.F, 0, 1};                  // queries: the frame's R regions + the CLS query as row R
-    Seg sgp{0, a.R, a.N, item % a.F, 0, 0};                 // the same without the CLS row (dQ rows written here)
-    const int h = (item / a.F) % a.H, b = item / (a.F * a.H);
-    const int64_t brow0 = (int64_t)b * a.N;
     const bf16* q = (const bf16*)a.q; const bf16* k = (const bf16*)a.k; const bf16* v = (const bf16*)a.v; const bf16* dout = (const bf16*)a.dout;
     bf16* dq = (bf16*)a.dq; bf16* dk = (bf16*)a.dk; bf16* dv = (bf16*)a.dv;
-    bf16* Ts = (bf16*)smraw + wid * (TROWS * VLD);
+    bf16* T1 = (bf16*)smraw + wid * (2 * TROWS * VLD);
+    bf16* T2 = T1 + TROWS * VLD;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const Seg sg{0, a.R, a.N, item % a.F, 0, 1};                // queries: the frame's R regions + the CLS query as row R
+    const Seg sgp{0, a.R, a.N, item % a.F, 0, 0};               // the same without the CLS row (dQ rows written here)
+    const int h = (item / a.F) % a.H, b = item / (a.F * a.H);
+    const int64_t brow0 = (int64_t)b * a.N;
+    bf16x8 qf[NT][2], gf[NT][2], kf[NT][2], vf[NT][2];
+    load_row_frags<NT>(qf, q, brow0, a.ld, h, sg, false, lane);
+    load_row_frags<NT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
+    load_row_frags<NT>(kf, k, brow0, a.ld, h, sg, true, lane);
+    load_row_frags<NT>(vf, v, brow0, a.ld, h, sg, true, lane);
+    float mlane;
+    { const int tok = sg.tok_k(lane); mlane = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
     const float* st3 = stats + ((int64_t)b * a.H + h) * 4;
     const float m_cls = st3[0], il_cls = 1.f / st3[1];
     float D_cls = st3[2];
@@ -880,31 +1054,215 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         const float pd = (float)((const bf16*)a.fwd_out)[brow0 * a.ld_fo + h * HD + lane] * (float)dout[brow0 * a.ldo + h * HD + lane];
         D_cls = wave_sum(pd);
     }
+    {
+        put_row_frags<NT, NTP>(T1, gf, lane);                    // dO -> tile 1 (dV pass), Q -> tile 2 (dK pass)
+        put_row_frags<NT, NTP>(T2, qf, lane);
+        f32x4 s2[NT][NT], dp[NT][NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][0], vf[kt][0], zero4, 0, 0, 0);
+                dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][1], vf[kt][1], acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][0], kf[kt][0], zero4, 0, 0, 0);
+                s2[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][1], kf[kt][1], acc, 0, 0, 0);
+            }
+        float mk[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) mk[kt] = __shfl(mlane, 16 * kt + c, 64);
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = 16 * qt + 4 * g + r;
+                const bool qok = sg.tok_q(qi) >= 0, is_cls = qi == a.R;
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) { s2[qt][kt][r] = s2[qt][kt][r] * a.scale + mk[kt]; m = fmaxf(m, s2[qt][kt][r]); }
+                m = row16_max(m);
+                if (is_cls) m = m_cls;                                       // the CLS query's softmax spans all N keys
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    float e = __expf(s2[qt][kt][r] - m);
+                    if (is_cls && kt == 0 && c == 0 && sg.f != 0) e = 0.f;    // CLS query x CLS key: counted once, in frame 0
+                    s2[qt][kt][r] = e; sum += e;
+                }
+                sum = row16_sum(sum);
+                const float inv = is_cls ? il_cls : (qok ? 1.f / sum : 0.f);      // padded query rows contribute nothing
+                float D = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) { s2[qt][kt][r] *= inv; D += s2[qt][kt][r] * dp[qt][kt][r]; }
+                D = row16_sum(D);
+                if (is_cls) D = D_cls;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) dp[qt][kt][r] = s2[qt][kt][r] * (dp[qt][kt][r] - D);   // dS
+            }
+        // P and dS as the bf16 A operands of the key-major products (k index = query: tiles 2 s, 2 s + 1)
+        bf16x8 pP[NS][NT], pS[NS][NT];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int qt0 = 2 * s, qt1 = 2 * s + 1;
+                pP[s][kt] = pack8(s2[qt0][kt], qt1 < NT ? s2[qt1 < NT ? qt1 : qt0][kt] : zero4);
+                pS[s][kt] = pack8(dp[qt0][kt], qt1 < NT ? dp[qt1 < NT ? qt1 : qt0][kt] : zero4);
+            }
+        // dV[key][d] = sum_q P[q][key] dO[q][d];  dK[key][d] = scale * sum_q dS[q][key] Q[q][d]
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            bf16* Ts = pass == 0 ? T1 : T2;
+            f32x4 acc[NT][4];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc[kt][dt] = zero4;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int qt0 = 2 * s, qt1 = 2 * s + 1;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 xb = tr_pair(lds_addr(&Ts[(16 * qt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                              lds_addr(&Ts[(16 * qt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 0 ? pP[s][kt] : pS[s][kt], xb, acc[kt][dt], 0, 0, 0);
+                }
+            }
+            const float mul = pass == 0 ? 1.f : a.scale;
+            bf16* dst = pass == 0 ? dv : dk;
+            if (g == 0) {          // key 0 of the frame = the shared CLS key: fp32 partial for launch C
+                float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + sg.f) * 2 + (pass == 0 ? 1 : 0)) * HD + c;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[0][dt][0] * mul;
+            }
+            emit_rows<NT>(Ts, acc, mul, dst, brow0, a.ldd, h, sg, true, lane);
+            if (a.csum) tile_colsum<NT>(Ts, sg, true, lane, a.csum + ((int64_t)b * a.F + sg.f) * (3 * a.H * HD) + (pass == 0 ? 2 : 1) * a.H * HD + h * HD);
+            if (pass == 0) put_row_frags<NT, NTP>(T1, kf, lane);  // tile 1 is free: K (held in registers so far) moves in, read back transposed for dQ
+        }
+        // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: K through tile 1 (transposing read, natural key order), dS through tile 2
+        bf16x8 kb[NS][4];
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                kb[ks][dt] = tr_pair(lds_addr(&T1[(32 * ks + 8 * g + qq) * VLD + 16 * dt + 4 * pp]),
+                                     lds_addr(&T1[(32 * ks + 8 * g + 4 + qq) * VLD + 16 * dt + 4 * pp]));
+        // (columns >= 16 NT of the rows written next keep finite values of the tile's previous use; they meet the zero K rows of the padded k-step)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int qt = 2 * s + (e >> 2), r = e & 3;
+                    if (qt < NT) T2[(16 * qt + 4 * g + r) * VLD + 16 * kt + c] = pS[s][kt][e];
+                }
+        f32x4 dqa[NT][4];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                const bf16x8 dsf = *(const bf16x8*)&T2[(16 * qt + c) * VLD + 32 * ks + 8 * g];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, kb[ks][dt], dqa[qt][dt], 0, 0, 0);
+            }
+        if (a.dq_ws) {       // dq of the CLS query: this frame's share (summed by attn_bwd_cls_post_kernel)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * qt + 4 * g + r == a.R) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) a.dq_ws[(int64_t)item * HD + 16 * dt + c] = dqa[qt][dt][r] * a.scale;
+                    }
+        }
+        emit_rows<NT>(T1, dqa, a.scale, dq, brow0, a.ldd, h, sgp, false, lane);
+        if (a.csum) tile_colsum<NT>(T1, sgp, false, lane, a.csum + ((int64_t)b * a.F + sgp.f) * (3 * a.H * HD) + h * HD);
+    }
+}
 
+// Round 5 -- space attention backward, bf16, the "lean" form of the kernel above (same products, same sums; see sattn_fwd_kernel for the
+// three ideas).  Every output product runs with its operands swapped (dV^T = dO^T P, dK^T = Q^T dS, dQ^T = K^T dS^T), so a lane holds four
+// consecutive channels of one key / query row: staging is one 8-byte LDS store per 16 x 16 tile, the CLS key's and the CLS query's
+// partials leave as 16-byte stores from the four lanes that hold them.  dS reaches the dQ product through the tile TRANSPOSED ([key][query],
+// 8-byte pieces straight from the packed registers, read back with the transposing read) instead of 36 two-byte stores.
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void sattn_bwd_kernel(AttnArgs a, int items, const float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    constexpr int NTP = (NT + 1) & ~1, TROWS = 16 * NTP, NS = NTP / 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wid));
+    if (item >= items) return;
+    const int R = a.R;
+    const int cq = R >> 4, cc = R & 15;
+    const int ldb = (int)a.ld * 2, ldob = (int)a.ldo * 2, lddb = (int)a.ldd * 2;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.q), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.k), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.v), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dout), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc(a.dq, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdk = __builtin_amdgcn_make_buffer_rsrc(a.dk, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdv = __builtin_amdgcn_make_buffer_rsrc(a.dv, 0, 0x7fffffff, 0x00020000);
+    bf16* T1 = (bf16*)smraw + wid * (2 * TROWS * VLD);
+    bf16* T2 = T1 + TROWS * VLD;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // one load phase: q / dO rows = the frame's regions + the CLS token as row R; k / v rows = CLS token, regions; rows past the end re-read
+    // token 0 (finite; masked below)
+    const int f = item % a.F, h = (item / a.F) % a.H, b = item / (a.F * a.H), fR = f * R;
+    const int soff = (b * a.N * (int)a.ld + h * HD) * 2, soffo = (b * a.N * (int)a.ldo + h * HD) * 2, soffd = (b * a.N * (int)a.ldd + h * HD) * 2;
     bf16x8 qf[NT][2], gf[NT][2], kf[NT][2], vf[NT][2];
-    load_row_frags<NT>(qf, q, brow0, a.ld, h, sg, false, lane);
-    load_row_frags<NT>(gf, dout, brow0, a.ldo, h, sg, false, lane);
-    load_row_frags<NT>(kf, k, brow0, a.ld, h, sg, true, lane);
-    load_row_frags<NT>(vf, v, brow0, a.ld, h, sg, true, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = 16 * t + c;
+        const int tq = i < R ? 1 + fR + i : 0, tk = i >= 1 && i <= R ? fR + i : 0;
+        qf[t][0] = buf_row16(rq, tq * ldb + 16 * g, soff); qf[t][1] = buf_row16(rq, tq * ldb + 16 * g + 64, soff);
+        gf[t][0] = buf_row16(rg, tq * ldob + 16 * g, soffo); gf[t][1] = buf_row16(rg, tq * ldob + 16 * g + 64, soffo);
+        kf[t][0] = buf_row16(rk, tk * ldb + 16 * g, soff); kf[t][1] = buf_row16(rk, tk * ldb + 16 * g + 64, soff);
+        vf[t][0] = buf_row16(rv, tk * ldb + 16 * g, soff); vf[t][1] = buf_row16(rv, tk * ldb + 16 * g + 64, soff);
+    }
+    const float mlane = lane <= R ? a.addmask[(int64_t)b * a.N + (lane == 0 ? 0 : fR + lane)] : -INFINITY;      // additive mask of key `lane`
+    const float* st3 = stats + ((int64_t)b * a.H + h) * 4;
+    const float m_cls = st3[0], il_cls = 1.f / st3[1];
+    float D_cls = st3[2];
+    if (a.fwd_out) {     // statistics saved by the forward: D = sum_j p_j <dO_cls, v_j> = <dO_cls, O_cls>
+        const float pd = (float)((const bf16*)a.fwd_out)[(int64_t)b * a.N * a.ld_fo + h * HD + lane] * (float)((const bf16*)a.dout)[(int64_t)b * a.N * a.ldo + h * HD + lane];
+        D_cls = wave_sum(pd);
+    }
+    put_row_frags<NT, NTP>(T1, gf, lane);                        // dO -> tile 1 (dV pass), Q -> tile 2 (dK pass)
+    put_row_frags<NT, NTP>(T2, qf, lane);
     f32x4 s2[NT][NT], dp[NT][NT];
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][0], kf[kt][0], zero4, 0, 0, 0);
-            s2[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][1], kf[kt][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][0], vf[kt][0], zero4, 0, 0, 0);
+            const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][0], vf[kt][0], zero4, 0, 0, 0);
             dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][1], vf[kt][1], acc, 0, 0, 0);
+        }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][0], kf[kt][0], zero4, 0, 0, 0);
+            s2[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][1], kf[kt][1], acc, 0, 0, 0);
         }
     float mk[NT];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) { const int tok = sg.tok_k(16 * kt + c); mk[kt] = tok >= 0 ? a.addmask[brow0 + tok] : -INFINITY; }
+    for (int kt = 0; kt < NT; ++kt) mk[kt] = __shfl(mlane, 16 * kt + c, 64);
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qi = 16 * qt + 4 * g + r;
-            const bool qok = sg.tok_q(qi) >= 0, is_cls = qi == a.R;
+            const bool qok = qi <= R, is_cls = qi == R;
             float m = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) { s2[qt][kt][r] = s2[qt][kt][r] * a.scale + mk[kt]; m = fmaxf(m, s2[qt][kt][r]); }
@@ -914,7 +1272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 float e = __expf(s2[qt][kt][r] - m);
-                if (is_cls && kt == 0 && c == 0 && sg.f != 0) e = 0.f;    // CLS query x CLS key: counted once, in frame 0
+                if (is_cls && kt == 0 && c == 0 && f != 0) e = 0.f;       // CLS query x CLS key: counted once, in frame 0
                 s2[qt][kt][r] = e; sum += e;
             }
             sum = row16_sum(sum);
@@ -927,93 +1285,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) dp[qt][kt][r] = s2[qt][kt][r] * (dp[qt][kt][r] - D);   // dS
         }
-    // dV[key][d] = sum_q P[q][key] dO[q][d];  dK[key][d] = scale * sum_q dS[q][key] Q[q][d]
+    // P and dS as bf16 operands of the key-major products (k index = query: tiles 2 s, 2 s + 1)
+    bf16x8 pP[NS][NT], pS[NS][NT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const int qt0 = 2 * s, qt1 = 2 * s + 1;
+            pP[s][kt] = pack8(s2[qt0][kt], qt1 < NT ? s2[qt1 < NT ? qt1 : qt0][kt] : zero4);
+            pS[s][kt] = pack8(dp[qt0][kt], qt1 < NT ? dp[qt1 < NT ? qt1 : qt0][kt] : zero4);
+        }
+    // dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key]: acc[kt][dt][r] = row (key 16 kt + c), channel 16 dt + 4 g + r
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 0) put_row_frags<NT, NTP>(Ts, gf, lane);
-        else {      // Q again from global (L2-warm): keeping its fragments alive across pass 0 costs 24 VGPRs at the kernel's peak
-            bf16x8 q2[NT][2];
-            load_row_frags<NT>(q2, q, brow0, a.ld, h, sg, false, lane);
-            put_row_frags<NT, NTP>(Ts, q2, lane);
-        }
+        bf16* Ts = pass == 0 ? T1 : T2;
         f32x4 acc[NT][4];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) acc[kt][dt] = zero4;
 #pragma unroll
-        for (int s = 0; s < NTP / 2; ++s) {
-            const int qt0 = 2 * s, qt1 = 2 * s + 1;
-            bf16x8 pa[NT];
+        for (int s = 0; s < NS; ++s) {
+            bf16x8 xb[4];
+            tr_quad(xb, lds_addr(&Ts[(32 * s + 4 * g + qq) * VLD + 4 * pp]), lds_addr(&Ts[(32 * s + 16 + 4 * g + qq) * VLD + 4 * pp]));
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                const f32x4& lo = pass == 0 ? s2[qt0][kt] : dp[qt0][kt];
-                const f32x4& hi = qt1 < NT ? (pass == 0 ? s2[qt1 < NT ? qt1 : qt0][kt] : dp[qt1 < NT ? qt1 : qt0][kt]) : zero4;
-                pa[kt] = pack8(lo, hi);
-            }
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 xb = tr_pair(lds_addr(&Ts[(16 * qt0 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]),
-                                          lds_addr(&Ts[(16 * qt1 + 4 * g + qq) * VLD + 16 * dt + 4 * pp]));
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt) acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[kt], xb, acc[kt][dt], 0, 0, 0);
-            }
+                for (int kt = 0; kt < NT; ++kt) acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[dt], pass == 0 ? pP[s][kt] : pS[s][kt], acc[kt][dt], 0, 0, 0);
         }
         const float mul = pass == 0 ? 1.f : a.scale;
-        bf16* dst = pass == 0 ? dv : dk;
-        if (g == 0) {          // key 0 of the frame = the shared CLS key: fp32 partial for launch C
-            float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + sg.f) * 2 + (pass == 0 ? 1 : 0)) * HD + c;
+        if (c == 0) {          // key 0 of the frame = the shared CLS key: fp32 partial for the closing launch
+            float* w = a.ws + ((((int64_t)b * a.H + h) * a.F + f) * 2 + (pass == 0 ? 1 : 0)) * HD + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) w[16 * dt] = acc[0][dt][0] * mul;
+            for (int dt = 0; dt < 4; ++dt) *(float4*)&w[16 * dt] = make_float4(acc[0][dt][0] * mul, acc[0][dt][1] * mul, acc[0][dt][2] * mul, acc[0][dt][3] * mul);
         }
-        emit_rows<NT>(Ts, acc, mul, dst, brow0, a.ldd, h, sg, true, lane);
-        if (a.csum) tile_colsum<NT>(Ts, sg, true, lane, a.csum + ((int64_t)b * a.F + sg.f) * (3 * a.H * HD) + (pass == 0 ? 2 : 1) * a.H * HD + h * HD);
-    }
-    // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: K through the tile (transposing read, natural key order), then dS
-    {               // K again from global (L2-warm), for the same reason
-        bf16x8 k2[NT][2];
-        load_row_frags<NT>(k2, k, brow0, a.ld, h, sg, true, lane);
-        put_row_frags<NT, NTP>(Ts, k2, lane);
-    }
-    bf16x8 kb[NTP / 2][4];
-#pragma unroll
-    for (int ks = 0; ks < NTP / 2; ++ks)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            kb[ks][dt] = tr_pair(lds_addr(&Ts[(32 * ks + 8 * g + qq) * VLD + 16 * dt + 4 * pp]),
-                                 lds_addr(&Ts[(32 * ks + 8 * g + 4 + qq) * VLD + 16 * dt + 4 * pp]));
-    // (columns >= 16 NT of the rows written next keep finite K values; they meet the zero K rows of the padded k-step)
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ts[(16 * qt + 4 * g + r) * VLD + 16 * kt + c] = (bf16)dp[qt][kt][r];
+            for (int dt = 0; dt < 4; ++dt) *(u32x2_t*)&Ts[(16 * kt + c) * VLD + 16 * dt + 4 * g] = pack4(acc[kt][dt] * mul);
+#pragma unroll
+        for (int it = 0; it < NT * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            if (row >= 1 && row <= R)
+                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t*)&Ts[row * VLD + ch * 8], pass == 0 ? rdv : rdk, (fR + row) * lddb + ch * 16, soffd, 0);
+        }
+        if (a.csum) {
+            const Seg sg{0, R, a.N, f, 0, 1};
+            tile_colsum<NT>(Ts, sg, true, lane, a.csum + ((int64_t)b * a.F + f) * (3 * a.H * HD) + (pass == 0 ? 2 : 1) * a.H * HD + h * HD);
+        }
+        if (pass == 0) put_row_frags<NT, NTP>(T1, kf, lane);    // tile 1 is free: K (held in registers so far) moves in, read back transposed for dQ
+    }
+    // dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]: K^T from tile 1, dS^T written to tile 2 as [key][query] and read back transposed
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const u32x4_t w = __builtin_bit_cast(u32x4_t, pS[s][kt]);
+            *(u32x2_t*)&T2[(16 * kt + c) * VLD + 32 * s + 4 * g] = (u32x2_t){w[0], w[1]};
+            if (2 * s + 1 < NT) *(u32x2_t*)&T2[(16 * kt + c) * VLD + 32 * s + 16 + 4 * g] = (u32x2_t){w[2], w[3]};
+        }
     f32x4 dqa[NT][4];
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = zero4;
 #pragma unroll
-    for (int ks = 0; ks < NTP / 2; ++ks)
-#pragma unroll
-        for (int qt = 0; qt < NT; ++qt) {
-            const bf16x8 dsf = *(const bf16x8*)&Ts[(16 * qt + c) * VLD + 32 * ks + 8 * g];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, kb[ks][dt], dqa[qt][dt], 0, 0, 0);
-        }
-    if (a.dq_ws) {       // dq of the CLS query: this frame's share (summed by attn_bwd_cls_post_kernel)
+    for (int ks = 0; ks < NS; ++ks) {
+        bf16x8 kb[4], dsb[4];
+        tr_quad(kb, lds_addr(&T1[(32 * ks + 8 * g + qq) * VLD + 4 * pp]), lds_addr(&T1[(32 * ks + 8 * g + 4 + qq) * VLD + 4 * pp]));
+        tr_quad(dsb, lds_addr(&T2[(32 * ks + 8 * g + qq) * VLD + 4 * pp]), lds_addr(&T2[(32 * ks + 8 * g + 4 + qq) * VLD + 4 * pp]));
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * qt + 4 * g + r == a.R) {
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) a.dq_ws[(int64_t)item * HD + 16 * dt + c] = dqa[qt][dt][r] * a.scale;
-                }
+            for (int dt = 0; dt < 4; ++dt) dqa[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[dt], dsb[qt], dqa[qt][dt], 0, 0, 0);
     }
-    emit_rows<NT>(Ts, dqa, a.scale, dq, brow0, a.ldd, h, sgp, false, lane);
-    if (a.csum) tile_colsum<NT>(Ts, sgp, false, lane, a.csum + ((int64_t)b * a.F + sgp.f) * (3 * a.H * HD) + h * HD);
+    if (a.dq_ws) {       // dq of the CLS query: this frame's share (summed by attn_bwd_cls_post_kernel)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+            if (qt == cq && c == cc) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *(float4*)&a.dq_ws[(int64_t)item * HD + 16 * dt + 4 * g] =
+                        make_float4(dqa[qt][dt][0] * a.scale, dqa[qt][dt][1] * a.scale, dqa[qt][dt][2] * a.scale, dqa[qt][dt][3] * a.scale);
+            }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(u32x2_t*)&T1[(16 * qt + c) * VLD + 16 * dt + 4 * g] = pack4(dqa[qt][dt] * a.scale);
+#pragma unroll
+    for (int it = 0; it < NT * 2; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        if (row < R)
+            __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t*)&T1[row * VLD + ch * 8], rdq, (1 + fR + row) * lddb + ch * 16, soffd, 0);
+    }
+    if (a.csum) {
+        const Seg sgp{0, R, a.N, f, 0, 0};
+        tile_colsum<NT>(T1, sgp, false, lane, a.csum + ((int64_t)b * a.F + f) * (3 * a.H * HD) + h * HD);
+    }
 }
 
 // launch A of the merged backward: CLS-query statistics and dq_cls.  stats[b][h] = (max, sum, D, -)
@@ -1349,15 +1718,24 @@ extern "C" int dvlp_attention_fwd_ex(int dtype, int mode, int64_t B, int64_t N, 
         // MFMA path for the frame / full segments; the single CLS query per (b, h) stays on the streaming VALU workgroup
         bool done = false;
 #define MFWD(NQT_, NKT_, ITEMS, QG) do { const int items_ = (int)(ITEMS); const size_t l_ = (size_t)4 * (((NKT_ + 1) & ~1) * 16 * VLD) * sizeof(bf16); \
-            (void)hipFuncSetAttribute((const void*)mattn_fwd_kernel<NQT_, NKT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            hipLaunchKernelGGL((mattn_fwd_kernel<NQT_, NKT_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_, (int)(QG)); done = true; } while (0)
+            constexpr int wpe_ = NKT_ <= 3 ? 4 : 2; \
+            (void)hipFuncSetAttribute((const void*)mattn_fwd_kernel<NQT_, NKT_, wpe_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipLaunchKernelGGL((mattn_fwd_kernel<NQT_, NKT_, wpe_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_, (int)(QG)); done = true; } while (0)
         if (mode == 0) {
             const int nqt = (int)cdiv(R, 16), nkt = (int)cdiv(R + 1, 16);
             // fold: the CLS row needs a free query slot in the frame tile (R + 1 <= 16 nqt)
             if (ext && workspace && cls_stats && g_attn_fold && nqt == nkt && nqt <= 3) {     // (ext: the caller must be able to learn that it happened)
                 a.cls_o = workspace; a.cls_st = workspace + B * H * F * HD; a.cls_stats = cls_stats;
             }
-            if (nqt == 3 && nkt == 3) MFWD(3, 3, B * H * F, 1);
+            const bool small = (int64_t)B * N * (ld > ldo ? ld : ldo) * 2 < (int64_t)0x7fffff00;       // 32-bit byte offsets inside a tensor
+            if (g_attn_lean && a.cls_o && small && !a.abl) {          // (the fold guarantees nqt == nkt <= 3)
+                const size_t l_ = (size_t)4 * (((nkt + 1) & ~1) * 16 * VLD) * sizeof(bf16); const int items_ = (int)(B * H * F);
+#define SFWD(NT_) hipLaunchKernelGGL((sattn_fwd_kernel<NT_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_)
+                if (nkt == 3) SFWD(3); else if (nkt == 2) SFWD(2); else SFWD(1);
+#undef SFWD
+                done = true;
+            }
+            else if (nqt == 3 && nkt == 3) MFWD(3, 3, B * H * F, 1);
             else if (nqt == 2 && nkt == 2) MFWD(2, 2, B * H * F, 1);
             else if (nqt == 1 && nkt == 1) MFWD(1, 1, B * H * F, 1);
             else if (nqt == 1 && nkt == 2) MFWD(1, 2, B * H * F, 1);
@@ -1424,9 +1802,17 @@ extern "C" int dvlp_attention_bwd_ex(int dtype, int mode, int64_t B, int64_t N, 
                     if (ext) ext->colsum_fused = a.csum != nullptr;
                 }
             } else hipLaunchKernelGGL(attn_bwd_cls_pre_kernel<bf16>, grid2, block, lds2, st, a, stats);
-#define MMRG(NT_) hipLaunchKernelGGL((mattn_bwd_space_merged_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, \
-                                     (size_t)4 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16), st, a, items, (const float*)stats)
-            if (nt == 3) MMRG(3); else if (nt == 2) MMRG(2); else MMRG(1);
+#define MMRG(NT_) do { const size_t l_ = (size_t)4 * 2 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16); \
+                (void)hipFuncSetAttribute((const void*)mattn_bwd_space_merged_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                hipLaunchKernelGGL((mattn_bwd_space_merged_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, l_, st, a, items, (const float*)stats); } while (0)
+#define SBWD(NT_) do { const size_t l_ = (size_t)4 * 2 * 16 * ((NT_ + 1) & ~1) * VLD * sizeof(bf16); \
+                (void)hipFuncSetAttribute((const void*)sattn_bwd_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                hipLaunchKernelGGL((sattn_bwd_kernel<NT_>), dim3((unsigned)cdiv(items, 4)), block, l_, st, a, items, (const float*)stats); } while (0)
+            const int64_t ldmax = ld > ldd ? (ld > ldo ? ld : ldo) : (ldd > ldo ? ldd : ldo);
+            const bool small = (int64_t)B * N * ldmax * 2 < (int64_t)0x7fffff00;       // 32-bit byte offsets inside a tensor
+            if (g_attn_lean && a.fwd_out && small) { if (nt == 3) SBWD(3); else if (nt == 2) SBWD(2); else SBWD(1); }
+            else if (nt == 3) MMRG(3); else if (nt == 2) MMRG(2); else MMRG(1);
+#undef SBWD
 #undef MMRG
             hipLaunchKernelGGL(attn_bwd_cls_post_kernel<bf16>, grid2, dim3(64), 0, st, a);
             return dvlp_launch_status();

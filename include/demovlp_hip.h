@@ -99,6 +99,8 @@ int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 /* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the
    three-launch form -- for A/B measurements and tests. */
 int dvlp_dev_attention_bwd_variant(int merged);
+/* space-mode bf16 with the CLS query folded: 1 (default) the round-5 kernels, 0 the round 3-4 ones -- for A/B measurements and tests */
+int dvlp_dev_attention_lean(int on);
 /* TIMING-ONLY ablation of the MFMA attention backward (1 no stores, 2 no exp, 4 stop after the softmax); 0 in production */
 int dvlp_dev_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */

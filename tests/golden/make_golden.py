@@ -492,6 +492,43 @@ def golden_retrieval(ref_model, ref_loss):
     np.savez_compressed(os.path.join(HERE, "g11_retrieval.npz"), **out)
 
 
+def golden_benchmark_curve(ref_model, ref_loss):
+    """G12: the imported reference's own fp32 loss curve AT THE BENCHMARK SIZE (B = 64, F = 8, R = 36: the configuration bench.py times and
+    BASELINE.json quotes the metric on) -- 5 optimisation steps driven as trainer/trainer_dist.py:144-171 drives them, HF-AdamW at the
+    config's lr (1e-5) and at the quirk's lr (2e-4), on the seeded batch `synthetic.fast_region_batch(64, 8, 36, seed=7)` +
+    `synthetic.caption_batch(64)` (pure functions of the seed: the GPU box rebuilds the inputs, only the curves are stored).  The
+    object mask goes in as float64, as the reference's numpy loader hands it over (WebVid_dataset.py:219-221)."""
+    F, R, B, STEPS = 8, 36, 64, 5
+    obj, mask = syn.fast_region_batch(B, F, R, seed=7)
+    ids, att = syn.caption_batch(B)
+    data = {"text": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(att)},
+            "object": torch.from_numpy(obj), "object_mask": torch.from_numpy(mask.astype(np.float64))}
+    out = {"F": F, "R": R, "B": B, "region_seed": 7}
+    import time
+    for tag, lr in (("lr1e-5", 1e-5), ("lr2e-4", 2e-4)):
+        m = build_reference_model(ref_model, F, R)
+        opt = HFAdamW(filter(lambda p: p.requires_grad, m.parameters()), lr=lr)
+        loss_fn = ref_loss.GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+        curve = []
+        for step in range(STEPS):
+            t0 = time.time()
+            opt.zero_grad()
+            o = m(data)
+            text_mask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+            text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+            gsim = ref_model.sim_matrix(o["global_text_embeddings"], o["global_object_embeddings"])
+            loss, gl, ll = loss_fn(gsim, o["local_object_embeddings"], o["local_text_embeddings"], o["object_mask"], text_length, text_mask)
+            loss.backward()
+            opt.step()
+            curve.append([loss.item(), gl.item(), ll.item()])
+            print("g12", tag, step, curve[-1], "%.1f s" % (time.time() - t0), flush=True)
+            del o, gsim, loss, gl, ll
+        out[tag] = np.array(curve, np.float64)
+        del m, opt
+    np.savez_compressed(os.path.join(HERE, "g12_benchmark_curve.npz"), **out)
+    print("g12 written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -510,6 +547,8 @@ def main():
             golden_qa(ref_model, ref_loss, ref_data, scratch)
         if "g11" in only:
             golden_retrieval(ref_model, ref_loss)
+        if "g12" in only:
+            golden_benchmark_curve(ref_model, ref_loss)
         return
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
@@ -523,6 +562,7 @@ def main():
     golden_eval(ref_model, ref_loss, ref_data, scratch)
     golden_qa(ref_model, ref_loss, ref_data, scratch)
     golden_retrieval(ref_model, ref_loss)
+    golden_benchmark_curve(ref_model, ref_loss)
 
 
 if __name__ == "__main__":

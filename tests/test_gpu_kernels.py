@@ -173,6 +173,36 @@ def test_space_attention(dtype, B, F, R, attn_bwd_variant):
     assert rel(dqkv[cls_rows], q.grad.reshape(B * N, 2304)[cls_rows]) < tol(dtype) * 2
 
 
+@pytest.mark.parametrize("B,F,R", [(5, 8, 36), (3, 4, 30), (4, 3, 15), (2, 2, 47)])
+def test_space_attention_round5_kernels_against_the_round4_kernels(B, F, R):
+    """Round 5's space-attention kernels (buffer addressing, output products with swapped operands, dS through the tile transposed) compute
+    the same sums as the round 3-4 kernels they replace: outputs, CLS statistics and gradients agree to bf16 rounding of identical fp32
+    values (observed: bit-equal), with ragged masks and the CLS row in every position of its tile."""
+    N = 1 + F * R
+    qkv = rnd(B * N, 2304, dtype=torch.bfloat16, scale=1.5)
+    mask01 = (torch.rand(B, N - 1, generator=torch.Generator().manual_seed(1)) > 0.2).float()
+    addmask = torch.cat([torch.zeros(B, 1), (mask01 - 1) * 100], 1).to(DEV)
+    dout = rnd(B * N, 768, dtype=torch.bfloat16, seed=2)
+    res = []
+    try:
+        for lean in (0, 1):
+            ops.call("dvlp_dev_attention_lean", lean)
+            out, stats = ops.space_attention_fwd(qkv, addmask, B, F, R, want_stats=True)
+            assert stats is not None
+            gqb = torch.zeros(2304, device=DEV)
+            dqkv, fused = ops.space_attention_bwd(qkv, addmask, dout, B, F, R, out=out, stats=stats, colsum_to=gqb)
+            if fused:
+                ops.flush_reductions()
+            torch.cuda.synchronize()
+            res.append((out, stats, dqkv, gqb if fused else dqkv.float().sum(0)))
+    finally:
+        ops.call("dvlp_dev_attention_lean", 1)
+    for x, y in zip(res[0], res[1]):
+        assert rel(y, x) < 2e-3, rel(y, x)
+    print("\nlean vs round-4 kernels: max |diff| out %.3g  stats %.3g  dqkv %.3g  colsum %.3g" % tuple(
+        float((x.float() - y.float()).abs().max()) for x, y in zip(res[0], res[1])))
+
+
 def test_space_attention_fold_switched_off():
     """dvlp_dev_attention_cls_fold(0): the forward leaves `cls_stats` untouched, says so in dvlp_attn_ext::folded, and the host hands no
     statistics to the backward (which then runs its own pass) -- never uninitialised ones."""

@@ -276,3 +276,21 @@ def test_oracle_vs_reference_on_the_retrieval_set_with_signal():
     for name, fn in (("t2v", metric.t2v_metrics), ("v2t", metric.v2t_metrics)):
         r = fn(g["o2t_sims"])
         assert np.allclose([r[k] for k in keys], g[name], rtol=1e-9, atol=1e-9), name
+
+
+def test_oracle_first_step_at_the_benchmark_size_vs_reference_g12():
+    """Golden G12 (the imported reference's 5-step curve at B = 64, F = 8, R = 36 -- the size bench.py times): the oracle's forward on the
+    same seeded batch reproduces the reference's first-step losses (the later steps need the B = 64 backward: ~10 GB and a minute per step
+    on the host, so the HIP path is held to the stored curve on the GPU box instead: tests/test_gpu_round5.py)."""
+    g = load_golden("g12_benchmark_curve.npz")
+    F, R, B = int(g["F"]), int(g["R"]), int(g["B"])
+    assert (F, R, B) == (8, 36, 64) and g["lr1e-5"].shape == (5, 3) and g["lr2e-4"].shape == (5, 3)
+    assert np.array_equal(g["lr1e-5"][0], g["lr2e-4"][0])            # step 1 sees the same weights at either learning rate
+    obj, mask = syn.fast_region_batch(B, F, R, seed=int(g["region_seed"]))
+    ids, att = syn.caption_batch(B)
+    p = orc.params_from_numpy(syn.fill_state_dict(F, R))
+    with torch.no_grad():
+        out = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask))
+        tm = (torch.from_numpy(att)[:, 1:].float() - 1.0) * 100.0
+        got = np.array([x.item() for x in orc.global_local_loss(out, tm, batched=True)[:3]])
+    assert np.abs(got - g["lr1e-5"][0]).max() < 2e-4, (got, g["lr1e-5"][0])
