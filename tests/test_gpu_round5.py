@@ -42,9 +42,11 @@ def _g12_batch(g):
                   "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
 
 
-# deviations observed on MI355X (printed by the test) -- bounds are ~2x:
-G12_FP32_TOL = {"lr1e-5": 1e-3, "lr2e-4": 1e-3}        # fp32 HIP path vs the reference, every step, all three losses, absolute (losses ~ 8-18)
-G12_BF16_TOL = {"lr1e-5": 1e-2, "lr2e-4": 3e-2}        # bf16 graph-replayed path, relative to the step's total loss
+# deviations observed on MI355X (printed by the test; the step is bit-reproducible, so they do not vary from box to box) -- bounds are ~3x:
+#   fp32: max |dev| over the five steps and three losses 7.6e-6 (lr 1e-5) / 1.6e-4 (lr 2e-4, whose step 3 jumps 17.9 -> 19.6) on losses of 8-19
+#   bf16: relative to the step's total loss 1.7e-4 (lr 1e-5) / 1.0e-3 (lr 2e-4)
+G12_FP32_TOL = {"lr1e-5": 3e-5, "lr2e-4": 5e-4}        # fp32 HIP path vs the reference, every step, all three losses, ABSOLUTE: inside north_star's 1e-3
+G12_BF16_TOL = {"lr1e-5": 5e-4, "lr2e-4": 3e-3}        # bf16 graph-replayed path, relative to the step's total loss
 
 
 @pytest.mark.parametrize("tag,lr", [("lr1e-5", 1e-5), ("lr2e-4", 2e-4)])
