@@ -131,21 +131,44 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def time_object_tower(model, data, steps, dist_sync, graph=True):
+def time_object_tower(model, data, steps, dist_sync, graph=True, part="object"):
     """ObjectTransformer alone, forward + backward (weight gradients included, no optimizer): seconds per pass.  This is the
     quantity BASELINE.json's north_star prices at >= 40 % of the bf16 MFMA peak (151.55 GFLOP per pair at F=8, R=36).
     ``graph``: the pass is captured once and replayed, like the step itself (the eager loop's ~350 launches cost the host about as
     long as the device needs for them, so an eager figure is partly a host figure); falls back to eager launches if capture fails.
+    ``part``: "object" (default), "text" (DistilBERT + txt_proj alone, forward + backward) or "loss" (sim_matrix + GlobalLocalLoss on fixed
+    embeddings, forward + backward) -- the other two terms of the step, timed the same way for the breakdown in the bench line.
     Returns (seconds per pass, "hipGraph replay" | "eager")."""
     import torch
     from demovlp_amd import functional as Fn, ops
     obj, mask = data["object"], data["object_mask"]
     state = {"dy": None}
+    if part == "loss":
+        from demovlp_amd.loss import GlobalLocalLoss
+        from demovlp_amd.model import sim_matrix
+        lf = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+        with torch.no_grad():
+            emb = model(data)
+        leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k != "object_mask") for k, v in emb.items()}
+        att = data["text"]["attention_mask"]
+        tmask, tlen = (att[:, 1:].contiguous() - 1.0) * 100.0, att.sum(1)
 
     def one():
-        for p in model.object_model.parameters():
+        if part == "loss":
+            for v in leaves.values():
+                v.grad = None
+            gs = sim_matrix(leaves["global_text_embeddings"], leaves["global_object_embeddings"])
+            loss = lf(gs, leaves["local_object_embeddings"], leaves["local_text_embeddings"], leaves["object_mask"], tlen, tmask)[0]
+            loss.backward()
+            return
+        mod = model.object_model if part == "object" else model
+        for p in mod.parameters():
             p.grad = None
-        emb, _ = model.object_model(obj, mask)
+        if part == "object":
+            emb, _ = model.object_model(obj, mask)
+        else:
+            g_, l_ = model.compute_text(data["text"])
+            emb = torch.cat([g_.unsqueeze(1), l_], 1)
         if state["dy"] is None:
             state["dy"] = torch.randn(emb.shape, device=emb.device, dtype=torch.float32).mul_(1e-3).to(emb.dtype)
         emb.backward(state["dy"])
@@ -256,6 +279,7 @@ def main():
         model.set_text_dropout(a.text_dropout)
     import demovlp_amd.functional as Fn
     Fn.OVERLAP_WGRAD = int(a.overlap_wgrad)
+    Fn.OVERLAP_TEXT_ONLY = bool(int(os.environ.get("DVLP_OVERLAP_TEXT_ONLY", "0")))
     if a.p8 >= 0:
         ops.call("dvlp_dev_gemm_p8_mode", a.p8)
     for kv in a.knob:
@@ -371,9 +395,14 @@ def main():
             mine = [(t, n) for t, n, piece in xt if piece == k]
             exchange.append({"piece": k, "mb": round(mine[0][1] / 2 ** 20, 1) if mine else 0.0,
                              "ms": round(sum(t for t, _ in mine) / len(mine), 3) if mine else 0.0})
-    obj_s, obj_mode = None, None
+    obj_s, obj_mode, text_s, loss_s = None, None, None, None
     if not a.no_object_tower:
         obj_s, obj_mode = time_object_tower(model, data, max(3, min(a.steps, 10)), sync, graph=use_graph)
+        try:          # the step's other two terms, timed the same way (breakdown only: a failure here must not cost the bench line)
+            text_s = time_object_tower(model, data, max(3, min(a.steps, 10)), sync, graph=use_graph, part="text")[0]
+            loss_s = time_object_tower(model, data, max(3, min(a.steps, 10)), sync, graph=use_graph, part="loss")[0]
+        except Exception as e:  # noqa: BLE001
+            print("tower breakdown failed: %s" % str(e)[:300], file=sys.stderr)
 
     if rank == 0:
         pairs = B * world * a.steps
@@ -447,6 +476,11 @@ def main():
                 out["roofline"]["object_transformer_launch_mode"] = obj_mode
                 out["roofline"]["object_transformer_tflops"] = round(B * fpp_obj / obj_s / 1e12, 2)
                 out["roofline"]["object_transformer_frac"] = round(B * fpp_obj / obj_s / 1e12 / peak, 4)
+            if text_s is not None and loss_s is not None:
+                # the step's other terms alone, same launch mode: text tower (26.15 GFLOP per pair) and sim_matrix + GlobalLocalLoss forward + backward
+                out["roofline"]["text_tower_ms"] = round(1e3 * text_s, 3)
+                out["roofline"]["text_tower_frac"] = round(B * 26.15e9 / text_s / 1e12 / peak, 4)
+                out["roofline"]["loss_heads_ms"] = round(1e3 * loss_s, 3)
         if not gemm_n and obj_s is not None:        # (--no-kernel-timing: no roofline object; the object tower's figure stands alone)
             out["object_transformer"] = {"ms": round(1e3 * obj_s, 3), "launch_mode": obj_mode, "tflops": round(B * fpp_obj / obj_s / 1e12, 2),
                                          "frac": round(B * fpp_obj / obj_s / 1e12 / peak, 4)}

@@ -64,6 +64,10 @@ OVERLAP_WGRAD = 0         # side-stream gradient work (needs gradient arenas): 0
                           # but each GEMM's own duration stretches, which blurs per-kernel timing)
 
 
+OVERLAP_TEXT_ONLY = False  # experiment: side-stream gradient work only for launches made on the text tower's stream (its 75-tile products
+                           # leave 70 % of the CUs to whatever runs beside them)
+
+
 class _Side:
     """Context: enqueue on the side stream everything that only feeds parameter gradients.  The tensors it reads were
     produced on the main stream, so the side stream first waits for the main stream's current position, and the caching
@@ -72,6 +76,9 @@ class _Side:
     def __init__(self, *tensors, level=1):
         self.tensors = tensors
         self.on = OVERLAP_WGRAD >= level and torch.cuda.is_available()
+        if self.on and OVERLAP_TEXT_ONLY:
+            dev = torch.cuda.current_device()
+            self.on = dev in ops._TEXT and ops._TEXT[dev] == torch.cuda.current_stream()
 
     def __enter__(self):
         if not self.on:
