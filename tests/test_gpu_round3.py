@@ -144,7 +144,7 @@ def _hand_averaged_reference():
     return _HAND_REF[0]
 
 
-@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), (8, 4, "bf16-buckets"), pytest.param(6, marks=pytest.mark.slow), None],
+@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), (8, 4, "bf16-buckets"), pytest.param(6, marks=pytest.mark.slow), pytest.param(None, marks=pytest.mark.slow)],
                          ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "three-graphs-bf16-buckets", "two-graphs-cut6", "one-graph"])
 def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     """Two processes on cuda:0, each with its own batch per step, five steps through GraphedTrainStep (two of them replays of the
@@ -847,17 +847,25 @@ def _graph_dp_bf16_worker(rank, world, port, q, cut, grad_dtype="float32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from demovlp_amd import functional as Fn
         F, R, B = 8, 36, 2
-        model = build(F, R, "bfloat16")
-        arena = ParamArena(model, bf16_shadow=True)
-        opt = FusedAdamW(arena, lr=1e-4)
-        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0, grad_dtype=grad_dtype)
-        losses = []
-        for s in range(7):
-            out = stepper(to_dev(*_np_batch(F, R, B, rank, s)))
-            losses.append(float(out[0].item()))                   # host synchronisation every step: each replay starts on an idle device
-            torch.cuda.synchronize()
-        q.put((rank, losses, arena.flat_p.double().cpu().numpy()[::211], float(arena.flat_p.double().sum().item())))
+        runs = []
+        for _ in range(2):            # the job twice, from scratch each time (fresh model, arena, optimizer state, graphs): run-to-run reproducibility
+            Fn.SHADOWS.clear()
+            model = build(F, R, "bfloat16")
+            arena = ParamArena(model, bf16_shadow=True)
+            opt = FusedAdamW(arena, lr=1e-4)
+            stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, cut=cut, bucket_mb=64.0, grad_dtype=grad_dtype)
+            losses = []
+            for s in range(7):
+                out = stepper(to_dev(*_np_batch(F, R, B, rank, s)))
+                losses.append(float(out[0].item()))                   # host synchronisation every step: each replay starts on an idle device
+                torch.cuda.synchronize()
+            assert stepper.graph is not None
+            runs.append((losses, arena.flat_p.double().cpu().numpy()[::211], float(arena.flat_p.double().sum().item())))
+            del stepper, opt, arena, model
+            torch.cuda.empty_cache()
+        q.put((rank, runs))
     except BaseException:  # noqa: BLE001
         q.put((rank, traceback.format_exc()))
     finally:
@@ -867,13 +875,12 @@ def _graph_dp_bf16_worker(rank, world, port, q, cut, grad_dtype="float32"):
 @pytest.mark.parametrize("grad_dtype", ["float32", pytest.param("bfloat16", marks=pytest.mark.slow)])
 def test_two_rank_bf16_graphed_step_with_host_sync_is_in_lock_step_and_reproducible(grad_dtype):
     """The data-parallel graph path in bf16 (three graphs, bucketed exchange, optimizer per bucket) with the loss read on the host every
-    step: the two ranks stay bit-equal, every loss is finite, and a second launch of the same job reproduces the first bit for bit.
+    step: the two ranks stay bit-equal, every loss is finite, and a second run of the same job (fresh model, arena, optimizer state and
+    graphs, in the same pair of processes) reproduces the first bit for bit.
     Gradient buckets cross as fp32 in the default run and as bf16 (cast kernel, bf16 sum, cast back) in the --runslow variant."""
-    runs = []
-    for _ in range(2):
-        (_, l0, p0, s0), (_, l1, p1, s1) = _spawn(_graph_dp_bf16_worker, ((8, 4), grad_dtype))
+    (_, r0), (_, r1) = _spawn(_graph_dp_bf16_worker, ((8, 4), grad_dtype))
+    for (l0, p0, s0), (l1, p1, s1) in zip(r0, r1):                                   # the two ranks, run by run: in lock step
         assert np.array_equal(p0, p1) and s0 == s1
         assert np.isfinite(l0).all() and np.isfinite(l1).all() and np.isfinite(p0).all()
-        runs.append((l0, l1, p0, s0))
-    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
-    assert np.array_equal(runs[0][2], runs[1][2]) and runs[0][3] == runs[1][3]
+    for r in (r0, r1):                                                               # each rank, first run against second: bit for bit
+        assert r[0][0] == r[1][0] and np.array_equal(r[0][1], r[1][1]) and r[0][2] == r[1][2]

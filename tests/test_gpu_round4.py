@@ -118,7 +118,10 @@ def test_bf16_evaluate_on_the_retrieval_set_with_signal_stays_within_stated_rank
 # measured on MI355X (profiles/r4_bf16_fidelity.txt), bounds = 2-2.5x the observation:
 #   lr 1e-5, 20 steps: max |loss16 - loss32| 3.4e-3 (1.9e-4 of the loss), |p16 - p32| = 0.115 |p32 - p0|, cos(update16, update32) 0.9934
 #   lr 2e-4, 10 steps: 4.6e-2 at the step-3 spike (2.4e-3 of the loss)
-@pytest.mark.parametrize("lr,steps,rel_tol,drift_tol,cos_min", [(1e-5, 20, 5e-4, 0.25, 0.98), (2e-4, 10, 6e-3, 0.6, 0.90)], ids=["lr1e-5", "lr2e-4"])
+# (HIP bf16 against HIP fp32: a drift bound, not parity -- the reference-anchored check at this size is golden G12, tests/test_gpu_round5.py;
+#  the lr 2e-4 variant runs with --runslow)
+@pytest.mark.parametrize("lr,steps,rel_tol,drift_tol,cos_min", [(1e-5, 20, 5e-4, 0.25, 0.98), pytest.param(2e-4, 10, 6e-3, 0.6, 0.90, marks=pytest.mark.slow)],
+                         ids=["lr1e-5", "lr2e-4"])
 def test_bf16_trains_like_fp32_at_the_benchmark_size(lr, steps, rel_tol, drift_tol, cos_min):
     from bf16_fidelity import fidelity
     r = fidelity(lr, steps=steps, B=64, verbose=False)
