@@ -741,6 +741,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     }
     const float mlane = lane <= R ? a.addmask[(int64_t)b * a.N + (lane == 0 ? 0 : fR + lane)] : -INFINITY;      // additive mask of key `lane`
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.abl & 8) {     // TIMING ONLY (tools/attn_bench.py): the kernel's memory traffic without its arithmetic -- every operand loaded, the output rows stored
+        bf16x8 acc8 = vfr[0][0];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc8 = acc8 + qf[t][0] + qf[t][1] + kf[t][0] + kf[t][1] + vfr[t][0] + vfr[t][1]; }
+#pragma unroll
+        for (int it = 0; it < NT * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            if (row < R) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc8), ro, (1 + fR + row) * ldob + ch * 16, soffo, 0);
+        }
+        if (mlane == 123.4567f) a.cls_st[0] = 1.f;
+        return;
+    }
     {
         f32x4 st[NT][NT];
 #pragma unroll
@@ -1728,7 +1740,7 @@ extern "C" int dvlp_attention_fwd_ex(int dtype, int mode, int64_t B, int64_t N, 
                 a.cls_o = workspace; a.cls_st = workspace + B * H * F * HD; a.cls_stats = cls_stats;
             }
             const bool small = (int64_t)B * N * (ld > ldo ? ld : ldo) * 2 < (int64_t)0x7fffff00;       // 32-bit byte offsets inside a tensor
-            if (g_attn_lean && a.cls_o && small && !a.abl) {          // (the fold guarantees nqt == nkt <= 3)
+            if (g_attn_lean && a.cls_o && small && !(a.abl & 7)) {          // (the fold guarantees nqt == nkt <= 3)
                 const size_t l_ = (size_t)4 * (((nkt + 1) & ~1) * 16 * VLD) * sizeof(bf16); const int items_ = (int)(B * H * F);
 #define SFWD(NT_) hipLaunchKernelGGL((sattn_fwd_kernel<NT_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_)
                 if (nkt == 3) SFWD(3); else if (nkt == 2) SFWD(2); else SFWD(1);

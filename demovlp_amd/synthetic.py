@@ -12,6 +12,7 @@ Schemas follow what the reference reads:
 """
 from __future__ import annotations
 
+import os
 import zlib
 
 import numpy as np
@@ -209,7 +210,12 @@ def fill_state_dict(num_frames: int, object_num: int, time_module=None, qa_label
         schema = state_dict_schema(num_frames, object_num, time_module)
         if qa_labels:
             schema.update(qa_head_schema(qa_labels))
-        hit = {k: fill_tensor(k, shp) for k, shp in schema.items()}
+        # (280 independent PCG64 streams; numpy's generators release the GIL: a few threads take the 4 s of a full-size model to ~1 s)
+        from concurrent.futures import ThreadPoolExecutor
+        names = list(schema)
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            vals = list(ex.map(lambda k: fill_tensor(k, schema[k]), names))
+        hit = dict(zip(names, vals))
         while len(_FILL_CACHE) >= _FILL_CACHE_MAX:
             _FILL_CACHE.pop(next(iter(_FILL_CACHE)))
         _FILL_CACHE[key] = hit

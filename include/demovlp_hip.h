@@ -101,7 +101,8 @@ int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 int dvlp_dev_attention_bwd_variant(int merged);
 /* space-mode bf16 with the CLS query folded: 1 (default) the round-5 kernels, 0 the round 3-4 ones -- for A/B measurements and tests */
 int dvlp_dev_attention_lean(int on);
-/* TIMING-ONLY ablation of the MFMA attention backward (1 no stores, 2 no exp, 4 stop after the softmax); 0 in production */
+/* TIMING-ONLY ablation of the MFMA attention kernels (backward, round 3-4 form: 1 no stores, 2 no exp, 4 stop after the softmax; forward,
+   round-5 form: 8 loads and stores only -- what the access shape alone costs); 0 in production */
 int dvlp_dev_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */
 int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,

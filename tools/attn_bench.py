@@ -50,5 +50,23 @@ def main():
         t = bench(lambda: ops.space_attention_bwd(qkv, mask, dout, B, F, R, out=out, stats=stats))
         print("CLS fold %d lean %d: space attention bwd  %7.1f us   (qkv + dout read, dqkv written: %.0f MB -> %.2f TB/s)" % (fold, per, t, 2 * mb + mb / 3, (2 * mb + mb / 3) / t))
 
+def traffic_only():
+    """The lean forward's loads and stores without its arithmetic (dvlp_dev_attention_ablate bit 8): what the access shape alone costs."""
+    B, F, R = 64, 8, 36
+    N = 1 + F * R
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B * N, 2304, device="cuda", generator=g).to(torch.bfloat16)
+    mask = torch.zeros(B, N, device="cuda")
+    mb = 2.0 * B * N * 2304 / 1e6
+    for abl in (0, 8, 0, 8):
+        ops.call("dvlp_dev_attention_ablate", abl)
+        t = bench(lambda: ops.space_attention_fwd(qkv, mask, B, F, R, want_stats=True))
+        print("ablate %d: lean forward %7.1f us  (%.2f TB/s of its 113 MB)" % (abl, t, (mb + mb / 3) / t))
+    ops.call("dvlp_dev_attention_ablate", 0)
+
+
 if __name__ == "__main__":
+    if os.environ.get("ATTN_TRAFFIC_ONLY"):
+        traffic_only()
+        sys.exit(0)
     main()
