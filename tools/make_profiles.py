@@ -85,7 +85,7 @@ if TRAFFIC_ONLY:
 mc = one("mfma/**/*counter_collection.csv")
 if mc:
     fam = lambda n: ("gemm_256x256 (p8)" if "p8_kernel" in n else "gemm_wgrad_group (p8g)" if "p8_group_kernel" in n else
-                     "gemm_128x128 (glds)" if "glds_kernel" in n else "attention_mfma" if "mattn" in n else
+                     "gemm_128x128 (glds)" if "glds_kernel" in n else "attention_space (sattn, round 5)" if "sattn" in n else "attention_mfma" if "mattn" in n else
                      "local_loss_softmax" if "xsoftmax" in n else "layernorm" if "ln_" in n else None)
     agg, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
     for r in csv.DictReader(open(mc)):
