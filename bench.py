@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FILES = ("r4_final_gemm_hbm_traffic_pmc.json", "r3_final_gemm_hbm_traffic_pmc.json", "r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
+TRAFFIC_FILES = ("r5_final_gemm_hbm_traffic_pmc.json", "r4_final_gemm_hbm_traffic_pmc.json", "r3_final_gemm_hbm_traffic_pmc.json", "r2_final_gemm_hbm_traffic_pmc.json", "r1_final_gemm_hbm_traffic_pmc.json")
 
 
 def csrc_sha():

@@ -1281,8 +1281,11 @@ static void launch_pair(bool bwd, int nkg, int nkw, dim3 grid, size_t lds, hipSt
 // The two directions of the loss (image->text / text->image) are independent between the softmax stages, and their contractions and
 // cosine passes are HBM-streaming kernels that reach 2.3-3.2 TB/s alone: the text->image half is issued on an internal side stream
 // beside the image->text half (fork / join by events -- legal inside a hipGraph capture), so the pair fills the memory system.
-// OFF by default (dvlp_dev_xattn_parallel_halves(1) / DVLP_XATTN_PARALLEL=1 switch it on).
-static int g_xpar = getenv("DVLP_XATTN_PARALLEL") ? 1 : 0;     // opt-in: -0.2 ms on the B = 64 backward alone, within noise in the step
+// ON by default since round 5 (dvlp_dev_xattn_parallel_halves(0) / DVLP_XATTN_PARALLEL=0 switch it off): -0.2 ms on the B = 64 backward alone
+// (round 3) and -0.13 ms in the replayed step, three alternating runs out of three (18.34 / 18.27 / 18.22 -> 18.18 / 18.11 / 18.15 ms: by
+// then the text tower's stream is idle, so the second half has the chip's spare CUs to itself).  The library's own side stream has no split-K
+// workspace registered (ops.py registers them per torch stream), so its products run unsplit: no slab is shared between the halves.
+static int g_xpar = (getenv("DVLP_XATTN_PARALLEL") && atoi(getenv("DVLP_XATTN_PARALLEL")) == 0) ? 0 : 1;
 extern "C" int dvlp_dev_xattn_parallel_halves(int on) { g_xpar = on; return DVLP_OK; }
 struct XFork {
     hipStream_t side = nullptr;

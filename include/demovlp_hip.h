@@ -229,7 +229,7 @@ int dvlp_dev_xattn_gram(int on);
    order -- for A/B measurements and tests */
 int dvlp_dev_xattn_pair_regions(int on);
 /* 1: the text->image half of the local loss (its contractions and cosine passes) is issued on an internal side stream beside the
-   image->text half between the softmax stages (fork / join by events, capturable); 0 (default): everything on the caller's stream */
+   image->text half between the softmax stages (fork / join by events, capturable; default since round 5); 0: everything on the caller's stream */
 int dvlp_dev_xattn_parallel_halves(int on);
 /* TIMING-ONLY ablation of the bf16 per-pair backward kernel: leave after stage 6 (launch + dP1 rows requested), 5 (S tile staged), 1 (+ norms),
    2 (image->text pass), 3 (text->image pass); 0 in production (tools/xbwd_stages.py) */

@@ -174,3 +174,39 @@ def test_one_rank_rccl_bf16_buckets_equal_the_fp32_exchange_of_bf16_rounded_grad
     assert sorted(k for _, _, k in r["pieces"]) == [0, 1, 2] and sum(nb for _, nb, _ in r["pieces"]) == 2 * r["elems"]
     assert all(ms > 0 for ms, _, _ in r["pieces"])
     assert r["steps"] == (5, 5) and np.isfinite(r["last"]).all()
+
+
+def test_local_loss_with_its_two_halves_on_two_streams_equals_the_single_stream_form():
+    """Round 5 default: the text->image half of the local loss (dvlp_xattn_fwd / _bwd) is issued on the library's own side stream beside the
+    image->text half (fork / join by events).  Same kernels on the same data -- only the side stream's products run without a K split (no
+    workspace is registered for that stream, so no slab is shared): scores equal bit for bit, gradients to bf16 rounding of one product."""
+    from demovlp_amd import ops
+    rng = np.random.default_rng(5)
+    Bi = Bj = 16
+    G, W = 288, 99
+    im = rng.standard_normal((Bi, G, 256), dtype=np.float32)
+    cap = rng.standard_normal((Bj, W, 256), dtype=np.float32)
+    for b in range(Bi):
+        cap[b, :W, :64] += 0.5 * im[b, :W, :64]
+    m_img = np.zeros((Bi, G), np.float32); m_img[::3, G - 5:] = -100
+    m_cap = np.full((Bj, W), -100.0, np.float32)
+    for b in range(Bj):
+        m_cap[b, : 6 + 2 * b] = 0
+    C, Q = torch.from_numpy(im).to(DEV).bfloat16(), torch.from_numpy(cap).to(DEV).bfloat16()
+    mi, mc = torch.from_numpy(m_img).to(DEV), torch.from_numpy(m_cap).to(DEV)
+    dsc = torch.from_numpy(rng.standard_normal((Bi, Bj)).astype(np.float32)).to(DEV)
+    res = []
+    try:
+        for par in (0, 1, 1):
+            ops.call("dvlp_dev_xattn_parallel_halves", par)
+            scores, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, 1, True)
+            dC, dQ = ops.xattn_bwd(C, Q, mi, mc, 20.0, 1, dsc, ws)
+            torch.cuda.synchronize()
+            res.append((scores.clone(), dC.clone(), dQ.clone()))
+    finally:
+        ops.call("dvlp_dev_xattn_parallel_halves", 1)
+    assert torch.equal(res[0][0], res[1][0])
+    for k in (1, 2):
+        d = float((res[1][k].float() - res[0][k].float()).abs().max()) / float(res[0][k].float().abs().max())
+        assert d < 8e-3, (k, d)                                          # one bf16 rounding of a differently ordered fp32 sum
+        assert torch.equal(res[1][k], res[2][k])                         # and the forked form reproduces itself
