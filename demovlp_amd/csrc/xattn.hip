@@ -19,6 +19,8 @@
 #include <cstdlib>
 
 constexpr int XD = 256;   // projection_dim (model/model.py:65)
+constexpr int64_t XSIDE_SLAB_BYTES = 64ll << 20;
+extern "C" int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes);
 
 extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                                  const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
@@ -32,6 +34,7 @@ struct XLayout {
     int64_t off_chat, off_qhat, off_S, off_P1, off_P2, off_wc, off_wc2, off_st1, off_st2, off_dP1, off_dP2, off_dchat, off_dqhat,
         off_dirc, off_dirq, off_rinv, off_cinv, off_rpart, off_cpart, total;
     int64_t off_chatp;                                   // Chat with its rows in xperm_g order (bf16 backward: dP1 comes out pair-ordered)
+    int64_t off_sideslab;                                // backward: fp32 split-K slabs of the side stream's products
     int64_t off_T, off_kq, off_dkq, off_u2, off_nc;      // Gram form: P2 Kq [Bj][Bi*G][Wp], Kq / dKq [Bj][Wp][Wp], u [Bj][Bi][G] f32, |C^| [Bi][G] f32
     bool gram;
 };
@@ -95,6 +98,9 @@ static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, 
         L.off_dqhat = take(Bj * L.Wp * XD * L.es);
         L.off_dirc = take(Bi * G * XD * 4);
         L.off_dirq = take(Bj * W * XD * 4);
+        // split-K slabs of the products issued on the library's own side stream (parallel halves): that stream must never fall back to the
+        // caller's default-stream GEMM workspace, which the main stream's split products may be using at the same moment
+        L.off_sideslab = take(XSIDE_SLAB_BYTES);
     }
     if (x_general(G, W)) {       // general-G path: reciprocal norms and partial dot products
         L.off_rinv = take(Bi * Bj * G * 4);
@@ -1300,8 +1306,12 @@ struct XFork {
         return true;
     }
     // returns the stream the second half should use (the caller's own stream when forking is off)
-    hipStream_t begin(hipStream_t st) {
+    // `slab` / `slab_bytes`: the split-K workspace the side stream's products may use (nullptr: they run unsplit).  Registered under the side
+    // stream's own key on every fork: a lookup for that stream must never fall through to the default-stream entry (round 5: it did, the
+    // main stream's split products were writing the same slabs, and at B = 16 the video-side gradients came back 80 % off now and then).
+    hipStream_t begin(hipStream_t st, void* slab = nullptr, int64_t slab_bytes = 0) {
         if (!ok()) return st;
+        (void)dvlp_set_workspace_stream((void*)side, slab ? slab : (void*)&g_xpar, slab ? slab_bytes : 0);
         (void)hipEventRecord(fork, st);
         (void)hipStreamWaitEvent(side, fork, 0);
         return side;
@@ -1468,7 +1478,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
             hipLaunchKernelGGL(xg_final_kernel<bf16>, gB, b256, lds3, st, ga); }
     }
     // dChat_i [G x d] = P1[i]^T [G x Bj*Wp] . dwc[i] [Bj*Wp x d]  +  dSraw[i] [G x Bj*Wp] . Qhat [Bj*Wp x d]
-    s2 = t_xfork.begin(st);
+    s2 = t_xfork.begin(st, ws + L.off_sideslab, XSIDE_SLAB_BYTES);
     XG(dtype, 1, 1, G, XD, Bj * Wp, P1, Gp, wc, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, Bj * Wp * XD,
        G * XD, 0, 0, stream);
     XG(dtype, 0, 1, G, XD, Bj * Wp, S, Bj * Wp, qhat, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bi, G * Bj * Wp, 0,

@@ -195,18 +195,29 @@ def test_local_loss_with_its_two_halves_on_two_streams_equals_the_single_stream_
     C, Q = torch.from_numpy(im).to(DEV).bfloat16(), torch.from_numpy(cap).to(DEV).bfloat16()
     mi, mc = torch.from_numpy(m_img).to(DEV), torch.from_numpy(m_cap).to(DEV)
     dsc = torch.from_numpy(rng.standard_normal((Bi, Bj)).astype(np.float32)).to(DEV)
+    # The hazard this test exists for (found by the full suite in round 5, 0.82 relative error in dC): the side stream's split-K products
+    # looked their slab workspace up, found none under their own stream and fell back to the DEFAULT-stream entry -- the very buffer the main
+    # stream's split products (at this batch size the video-side gradient products split too) were writing at that moment.  So: make sure
+    # that entry exists (a small split-K weight gradient on the default stream registers it), then compare the forms several times over.
+    gw = ops.linear_bwd_weight(torch.randn(4096, 256, device=DEV).bfloat16(), torch.randn(4096, 256, device=DEV).bfloat16())
+    assert torch.isfinite(gw).all()
     res = []
     try:
-        for par in (0, 1, 1):
+        for par in (0, 1, 1, 0, 1, 1, 1):
             ops.call("dvlp_dev_xattn_parallel_halves", par)
             scores, ws = ops.xattn_fwd(C, Q, mi, mc, 20.0, 1, True)
             dC, dQ = ops.xattn_bwd(C, Q, mi, mc, 20.0, 1, dsc, ws)
             torch.cuda.synchronize()
-            res.append((scores.clone(), dC.clone(), dQ.clone()))
+            res.append((par, scores.clone(), dC.clone(), dQ.clone()))
     finally:
         ops.call("dvlp_dev_xattn_parallel_halves", 1)
-    assert torch.equal(res[0][0], res[1][0])
-    for k in (1, 2):
-        d = float((res[1][k].float() - res[0][k].float()).abs().max()) / float(res[0][k].float().abs().max())
-        assert d < 8e-3, (k, d)                                          # one bf16 rounding of a differently ordered fp32 sum
-        assert torch.equal(res[1][k], res[2][k])                         # and the forked form reproduces itself
+    single = [r for r in res if r[0] == 0]
+    forked = [r for r in res if r[0] == 1]
+    for r in res[1:]:
+        assert torch.equal(r[1], res[0][1])                                # scores: bit for bit, either form
+    for k in (2, 3):
+        assert torch.equal(single[0][k], single[1][k])
+        for r in forked[1:]:
+            assert torch.equal(r[k], forked[0][k])                         # the forked form reproduces itself, run after run
+        d = float((forked[0][k].float() - single[0][k].float()).abs().max()) / float(single[0][k].float().abs().max())
+        assert d < 8e-3, (k, d)                                            # ... and differs from the single-stream form by one bf16 rounding of a differently split fp32 sum
