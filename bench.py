@@ -335,6 +335,7 @@ def main():
     timing_inline = not a.no_kernel_timing and not use_graph
     if timing_inline:
         model.parallel_towers = False                    # per-launch event timings need one stream
+        ops.call("dvlp_dev_xattn_parallel_halves", 0)
         ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -349,6 +350,7 @@ def main():
         # per-launch HIP events cannot be recorded inside a captured graph: the GEMM family is timed over an equally long EAGER
         # region right behind the replayed one (same kernels, same shapes, same launch order, the stream they are launched on)
         model.parallel_towers = False                # one stream: per-launch event timings are only meaningful without concurrent kernels
+        ops.call("dvlp_dev_xattn_parallel_halves", 0)   # (the local loss' two halves too: beside each other their products stretch one another)
         stepper._eager(data)
         sync()
         ops.prof_enable(True)
@@ -357,6 +359,7 @@ def main():
             stepper._eager(data)
         sync()
         eager_ms = 1e3 * (time.perf_counter() - t1) / a.steps
+        ops.call("dvlp_dev_xattn_parallel_halves", int(os.environ.get("DVLP_XATTN_PARALLEL", "1") != "0"))
     ops.prof_enable(False)
     gemm_ms, gemm_flops, gemm_n = ops.prof_collect() if not a.no_kernel_timing else (0.0, 0.0, 0)
 
