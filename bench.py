@@ -228,6 +228,9 @@ def main():
                     help="1 (default): the step runs as one captured hipGraph (GraphedTrainStep; gradient all-reduce outside the graph "
                          "when N > 1); 0: eager launches with the hook-driven, backward-overlapped GradReducer")
     ap.add_argument("--rccl-channels", type=int, default=0, help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS); 0 = RCCL's default")
+    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "rs_ag"],
+                    help="gradient exchange of the graph step: RCCL all_reduce per bucket (default) or reduce_scatter + all_gather per bucket (the direct, "
+                         "all-links form: DESIGN section 5; unmeasured on > 1 GPU)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1, graph mode: dtype of the gradient buckets on the links (bf16 = half the bytes; moments and master weights stay fp32)")
     ap.add_argument("--gather-negatives", action="store_true",
@@ -295,7 +298,8 @@ def main():
     model.parallel_towers = bool(a.parallel_towers)
     reducer, stepper = None, None
     if use_graph:
-        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist, grad_dtype="bfloat16" if a.grad_dtype == "bf16" else "float32")
+        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist, grad_dtype="bfloat16" if a.grad_dtype == "bf16" else "float32",
+                                   exchange=a.exchange)
     elif world > 1 or force_dist:
         reducer = GradReducer(arena, bucket_mb=64.0, always_reduce=force_dist)
 
@@ -437,6 +441,7 @@ def main():
             if exchange is not None:
                 out["grad_exchange_pieces"] = exchange          # time each piece's collectives occupy the communication stream (all but the last run beside the next graph)
                 out["grad_exchange_dtype"] = a.grad_dtype
+                out["grad_exchange"] = a.exchange
             if use_graph and getattr(stepper, "graph2", None) is not None:
                 sizes = [sum(hi - lo for lo, hi in runs) * 4 >> 20 for runs in stepper.piece_runs]
                 out["grad_exchange"] = ("backward captured as %d graphs cut at object blocks %s: the gradients a piece finishes (%s MB: text tower + top blocks first, "

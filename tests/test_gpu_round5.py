@@ -119,18 +119,21 @@ def _rccl_bucket_worker(port, q):
         data = {"text": {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(att).to(DEV)},
                 "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
         res = {}
-        for gd in ("float32", "bfloat16"):
+        for gd, xch in (("float32", "all_reduce"), ("bfloat16", "all_reduce"), ("float32", "rs_ag"), ("bfloat16", "rs_ag")):
             Fn.SHADOWS.clear()
             model = _build(F, R, "bfloat16")
             arena = ParamArena(model, bf16_shadow=True)
             opt = FusedAdamW(arena, lr=1e-4)
             lf = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
-            st = GraphedTrainStep(model, lf, opt, warmup=2, always_reduce=True, cut=(8, 4), bucket_mb=64.0, grad_dtype=gd, time_exchange=(gd == "bfloat16"))
+            st = GraphedTrainStep(model, lf, opt, warmup=2, always_reduce=True, cut=(8, 4), bucket_mb=64.0, grad_dtype=gd, time_exchange=(gd == "bfloat16"),
+                                  exchange=xch)
             assert st.collective and len(st.piece_runs) == 3
+            if xch == "rs_ag":
+                gd = gd + "/rs_ag"
             p0 = arena.flat_p.clone()
             loss1 = float(st(data)[0].item())                           # ONE step from identical weights
             torch.cuda.synchronize()
-            xt = st.exchange_times() if gd == "bfloat16" else []
+            xt = st.exchange_times() if gd.startswith("bfloat16") else []
             res[gd] = (loss1, arena.flat_g.clone(), arena.flat_p.clone(), p0, xt)
             for _ in range(4):                                          # ... then through the capture and two replays: must stay finite and in step
                 last = float(st(data)[0].item())
@@ -139,6 +142,10 @@ def _rccl_bucket_worker(port, q):
             res[gd] += (last, int(opt.step_count))
         g32, g16 = res["float32"][1], res["bfloat16"][1]
         q.put((0, dict(
+            rs_ag_fp32_equal=bool(torch.equal(res["float32/rs_ag"][1], g32) and torch.equal(res["float32/rs_ag"][2], res["float32"][2])),
+            rs_ag_bf16_equal=bool(torch.equal(res["bfloat16/rs_ag"][1], g16) and torch.equal(res["bfloat16/rs_ag"][2], res["bfloat16"][2])),
+            rs_ag_pieces=[(round(ms, 4), int(nb), int(k)) for ms, nb, k in res["bfloat16/rs_ag"][4]],
+            rs_ag_last=(res["float32/rs_ag"][5], res["bfloat16/rs_ag"][5]),
             loss_equal=res["float32"][0] == res["bfloat16"][0],
             grad_is_bf16_of_fp32=bool(torch.equal(g16, g32.to(torch.bfloat16).float())),
             grad_changed=bool((g16 != g32).any().item()),
@@ -154,7 +161,8 @@ def _rccl_bucket_worker(port, q):
 
 
 def test_one_rank_rccl_bf16_buckets_equal_the_fp32_exchange_of_bf16_rounded_gradients():
-    """GraphedTrainStep over RCCL with one rank (always_reduce): with grad_dtype='bfloat16' every bucket goes cast kernel -> all_reduce (bf16)
+    """(Also: the reduce-scatter + all-gather form of the exchange, fp32 and bf16, against the all-reduce form.)
+    GraphedTrainStep over RCCL with one rank (always_reduce): with grad_dtype='bfloat16' every bucket goes cast kernel -> all_reduce (bf16)
     -> cast kernel -> fused AdamW on three streams.  One rank's sum is the identity, so the gradient arena the optimizer reads must be
     EXACTLY bf16(g) of the fp32-bucket run's g -- any mis-ordering of the chain (a cast reading a bucket the collective has not finished,
     the optimizer running ahead of the cast back) shows as a mismatch.  The events of time_exchange cover every piece, with the bytes of a
@@ -172,6 +180,12 @@ def test_one_rank_rccl_bf16_buckets_equal_the_fp32_exchange_of_bf16_rounded_grad
     assert r["grad_changed"] and r["grad_is_bf16_of_fp32"]
     assert 0 < r["p_rel"] < 0.5                                         # the update moved, by less than half the step (AdamW normalises tiny gradients)
     assert sorted(k for _, _, k in r["pieces"]) == [0, 1, 2] and sum(nb for _, nb, _ in r["pieces"]) == 2 * r["elems"]
+    # exchange='rs_ag' (in-place reduce_scatter_tensor + all_gather_into_tensor per bucket; bf16: fp32 scatter, bf16 gather): with one rank
+    # both collectives are identities, so the arena and the updated parameters must equal the all-reduce runs' bit for bit -- what this
+    # checks is the plumbing (in-place shard views, the scatter -> cast -> gather -> cast -> AdamW ordering over three streams)
+    assert r["rs_ag_fp32_equal"] and r["rs_ag_bf16_equal"]
+    assert sorted(k for _, _, k in r["rs_ag_pieces"]) == [0, 1, 2] and sum(nb for _, nb, _ in r["rs_ag_pieces"]) == 3 * r["elems"]
+    assert np.isfinite(r["rs_ag_last"]).all() and r["rs_ag_last"] == r["last"]
     assert all(ms > 0 for ms, _, _ in r["pieces"])
     assert r["steps"] == (5, 5) and np.isfinite(r["last"]).all()
 
