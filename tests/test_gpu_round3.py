@@ -144,7 +144,9 @@ def _hand_averaged_reference():
     return _HAND_REF[0]
 
 
-@pytest.mark.parametrize("cut", [(8, 4), (8, 4, "side-stream"), (8, 4, "bf16-buckets"), pytest.param(6, marks=pytest.mark.slow), pytest.param(None, marks=pytest.mark.slow)],
+# (default run: the bench's configuration and its bf16-bucket variant; the gradient-side-stream mode (off in bench.py), two graphs and one graph with --runslow)
+@pytest.mark.parametrize("cut", [(8, 4), pytest.param((8, 4, "side-stream"), marks=pytest.mark.slow), (8, 4, "bf16-buckets"), pytest.param(6, marks=pytest.mark.slow),
+                                 pytest.param(None, marks=pytest.mark.slow)],
                          ids=["three-graphs-cuts8-4", "three-graphs-wgrad-side-stream", "three-graphs-bf16-buckets", "two-graphs-cut6", "one-graph"])
 def test_two_rank_graphed_step_matches_hand_averaged_gradients(cut):
     """Two processes on cuda:0, each with its own batch per step, five steps through GraphedTrainStep (two of them replays of the
