@@ -710,50 +710,64 @@ __device__ __forceinline__ u32x2_t pack4(const f32x4& a) {
     return (u32x2_t){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
 }
 
+// One WORKGROUP per (batch, head): eight waves, wave w takes frames w, w + 8, ...  The CLS query's per-frame partials (normalised output over
+// the frame's keys + (max, sum)) therefore meet in LDS: after one barrier wave 0 merges them flash-style, in frame order -- exactly what
+// attn_fwd_cls_combine_kernel did from global memory one launch later (bit-equal; that 64-thread launch, its ~1.5 us boundary and the partials'
+// round trip through memory are gone).  The padded fourth key tile of a 37-key frame is one zero tile shared by the workgroup, so a wave's
+// tile is 48 rows: 8 x 6.9 KB + 2.3 KB + F x 264 B per workgroup, two workgroups per CU.
+constexpr int SATTN_WAVES = 8;
 template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sattn_fwd_kernel(AttnArgs a, int items) {
+__global__ __launch_bounds__(64 * SATTN_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void sattn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     constexpr int NTP = (NT + 1) & ~1;
+    constexpr int TILE = NT * 16 * VLD;                          // elements per wave tile (no padding rows: see the zero tile)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wid));
-    if (item >= items) return;                                   // wave-uniform: EXEC stays full for the tr-reads
+    const int bh = (int)blockIdx.x, h = bh % a.H, b = bh / a.H;
     const int R = a.R;
-    const bool fold = a.cls_o != nullptr;                        // the CLS query is query row R of this frame's tile
     const int cq = R >> 4, cc = R & 15;
     const int ldb = (int)a.ld * 2, ldob = (int)a.ldo * 2;
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.q), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.k), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.v), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);
-    bf16* Vs = (bf16*)smraw + wid * (NTP * 16 * VLD);
-    // one load phase: q (rows = the frame's regions, + the CLS token as row R), k / v (row 0 = the CLS token, rows 1..R the regions);
-    // rows past the end re-read token 0 (finite values; their scores are masked / their outputs not written)
-    const int f = item % a.F, h = (item / a.F) % a.H, b = item / (a.F * a.H), fR = f * R;
+    bf16* Vs = (bf16*)smraw + wid * TILE;
+    bf16* Zt = (bf16*)smraw + SATTN_WAVES * TILE;                // 16 zero rows: the second half of an odd tile count's last k-step
+    const bool merge_here = gridDim.y == 1;                      // every frame of this (batch, head) is in this workgroup
+    float* slot_o = (float*)(Zt + 16 * VLD);                     // [8][64] the CLS row's partial outputs
+    float* slot_st = slot_o + SATTN_WAVES * HD;                  // [8][2]  (max, sum) over the frame's keys
+    if (NT != NTP) {
+        for (int i = threadIdx.x; i < 16 * VLD / 8; i += blockDim.x) *(uint4*)&Zt[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
     const int soff = (b * a.N * (int)a.ld + h * HD) * 2, soffo = (b * a.N * (int)a.ldo + h * HD) * 2;
-    bf16x8 qf[NT][2], kf[NT][2], vfr[NT][2];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int i = 16 * t + c;
-        const int vq = (i < R ? 1 + fR + i : 0) * ldb + 16 * g, vk = (i >= 1 && i <= R ? fR + i : 0) * ldb + 16 * g;
-        qf[t][0] = buf_row16(rq, vq, soff); qf[t][1] = buf_row16(rq, vq + 64, soff);
-        kf[t][0] = buf_row16(rk, vk, soff); kf[t][1] = buf_row16(rk, vk + 64, soff);
-        vfr[t][0] = buf_row16(rv, vk, soff); vfr[t][1] = buf_row16(rv, vk + 64, soff);
-    }
-    const float mlane = lane <= R ? a.addmask[(int64_t)b * a.N + (lane == 0 ? 0 : fR + lane)] : -INFINITY;      // additive mask of key `lane`
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if (a.abl & 8) {     // TIMING ONLY (tools/attn_bench.py): the kernel's memory traffic without its arithmetic -- every operand loaded, the output rows stored
-        bf16x8 acc8 = vfr[0][0];
+    const int f = (int)blockIdx.y * SATTN_WAVES + wid;
+    if (f < a.F) {                                               // (wave-uniform: EXEC stays full for the tr-reads)
+        const int fR = f * R;
+        // one load phase: q (rows = the frame's regions, + the CLS token as row R), k / v (row 0 = the CLS token, rows 1..R the regions);
+        // rows past the end re-read token 0 (finite values; their scores are masked / their outputs not written)
+        bf16x8 qf[NT][2], kf[NT][2], vfr[NT][2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc8 = acc8 + qf[t][0] + qf[t][1] + kf[t][0] + kf[t][1] + vfr[t][0] + vfr[t][1]; }
-#pragma unroll
-        for (int it = 0; it < NT * 2; ++it) {
-            const int row = it * 8 + (lane >> 3), ch = lane & 7;
-            if (row < R) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc8), ro, (1 + fR + row) * ldob + ch * 16, soffo, 0);
+        for (int t = 0; t < NT; ++t) {
+            const int i = 16 * t + c;
+            const int vq = (i < R ? 1 + fR + i : 0) * ldb + 16 * g, vk = (i >= 1 && i <= R ? fR + i : 0) * ldb + 16 * g;
+            qf[t][0] = buf_row16(rq, vq, soff); qf[t][1] = buf_row16(rq, vq + 64, soff);
+            kf[t][0] = buf_row16(rk, vk, soff); kf[t][1] = buf_row16(rk, vk + 64, soff);
+            vfr[t][0] = buf_row16(rv, vk, soff); vfr[t][1] = buf_row16(rv, vk + 64, soff);
         }
-        if (mlane == 123.4567f) a.cls_st[0] = 1.f;
-        return;
-    }
-    {
+        const float mlane = lane <= R ? a.addmask[(int64_t)b * a.N + (lane == 0 ? 0 : fR + lane)] : -INFINITY;      // additive mask of key `lane`
+        if (a.abl & 8) {     // TIMING ONLY (tools/attn_bench.py): the kernel's memory traffic without its arithmetic -- every operand loaded, the output rows stored
+            bf16x8 acc8 = vfr[0][0];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc8 = acc8 + qf[t][0] + qf[t][1] + kf[t][0] + kf[t][1] + vfr[t][0] + vfr[t][1]; }
+#pragma unroll
+            for (int it = 0; it < NT * 2; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                if (row < R) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc8), ro, (1 + fR + row) * ldob + ch * 16, soffo, 0);
+            }
+            if (mlane == 123.4567f) a.cls_stats[0] = 1.f;
+            return;
+        }
         f32x4 st[NT][NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
                 const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[qt][0], zero4, 0, 0, 0);
                 st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], qf[qt][1], acc, 0, 0, 0);
             }
-        put_row_frags<NT, NTP>(Vs, vfr, lane);
+        put_row_frags<NT, NT>(Vs, vfr, lane);
         float mk[NT][4];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -778,7 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
                 for (int r = 0; r < 4; ++r) {
                     st[kt][qt][r] = st[kt][qt][r] * a.scale + mk[kt][r];
                     // CLS query x CLS key belongs to frame 0's partial only
-                    if (kt == 0 && r == 0 && fold && qt == cq && c == cc && g == 0 && f != 0) st[kt][qt][r] = -INFINITY;
+                    if (kt == 0 && r == 0 && qt == cq && c == cc && g == 0 && f != 0) st[kt][qt][r] = -INFINITY;
                     m = fmaxf(m, st[kt][qt][r]);
                 }
             m = col4_max(m);
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { st[kt][qt][r] = __expf(st[kt][qt][r] - m); sum += st[kt][qt][r]; }
             sum = col4_sum(sum);
-            if (fold && qt == cq && c == cc && g == 0) { a.cls_st[2 * (int64_t)item] = m; a.cls_st[2 * (int64_t)item + 1] = sum; }
+            if (qt == cq && c == cc && g == 0) { slot_st[2 * wid] = m; slot_st[2 * wid + 1] = sum; }
             const float inv = 1.f / sum;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
@@ -806,21 +820,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
 #pragma unroll
         for (int s = 0; s < NTP / 2; ++s) {
             bf16x8 vb[4];
-            tr_quad(vb, lds_addr(&Vs[(32 * s + 4 * g + qq) * VLD + 4 * pp]), lds_addr(&Vs[(32 * s + 16 + 4 * g + qq) * VLD + 4 * pp]));
+            const bf16* hi = 2 * s + 1 < NT ? &Vs[(32 * s + 16 + 4 * g + qq) * VLD + 4 * pp] : &Zt[(4 * g + qq) * VLD + 4 * pp];
+            tr_quad(vb, lds_addr(&Vs[(32 * s + 4 * g + qq) * VLD + 4 * pp]), lds_addr(hi));
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[dt], pa[s][qt], o[qt][dt], 0, 0, 0);
         }
-        if (fold) {          // the CLS row's partial (normalised over this frame's keys) stays fp32: merged by attn_fwd_cls_combine_kernel
+        // the CLS row's partial (normalised over this frame's keys) stays fp32, in this wave's LDS slot
 #pragma unroll
-            for (int qt = 0; qt < NT; ++qt)
-                if (qt == cq && c == cc) {
+        for (int qt = 0; qt < NT; ++qt)
+            if (qt == cq && c == cc) {
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-                        *(float4*)&a.cls_o[(int64_t)item * HD + 16 * dt + 4 * g] = make_float4(o[qt][dt][0], o[qt][dt][1], o[qt][dt][2], o[qt][dt][3]);
-                }
-        }
+                for (int dt = 0; dt < 4; ++dt)
+                    *(float4*)&slot_o[wid * HD + 16 * dt + 4 * g] = make_float4(o[qt][dt][0], o[qt][dt][1], o[qt][dt][2], o[qt][dt][3]);
+            }
         // stage the frame's rows in the tile (8-byte pieces), leave as whole 128-byte head rows
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt)
@@ -832,6 +846,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             if (row < R)
                 __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4_t*)&Vs[row * VLD + ch * 8], ro, (1 + fR + row) * ldob + ch * 16, soffo, 0);
         }
+    }
+    if (!merge_here) {   // more than eight frames: this wave's partial goes to global memory for the combine launch
+        if (f < a.F) {
+            const int64_t item = (int64_t)bh * a.F + f;
+            a.cls_o[item * HD + lane] = slot_o[wid * HD + lane];
+            if (lane < 2) a.cls_st[2 * item + lane] = slot_st[2 * wid + lane];
+        }
+        return;
+    }
+    __syncthreads();
+    if (wid == 0) {      // the CLS query's output: out = sum_f w_f o_f, w_f = l_f e^(m_f - M) / L; (M, L) kept for the backward
+        float M = -INFINITY;
+        for (int w8 = 0; w8 < a.F; ++w8) M = fmaxf(M, slot_st[2 * w8]);
+        float L = 0.f, acc = 0.f;
+        for (int w8 = 0; w8 < a.F; ++w8) { const float w = slot_st[2 * w8 + 1] * __expf(slot_st[2 * w8] - M); L += w; acc += w * slot_o[w8 * HD + lane]; }
+        ((bf16*)a.out)[(int64_t)b * a.N * a.ldo + h * HD + lane] = (bf16)(acc / L);
+        if (lane == 0) { float* s4 = a.cls_stats + (int64_t)bh * 4; s4[0] = M; s4[1] = L; s4[2] = 0.f; s4[3] = 0.f; }
     }
 }
 
@@ -1741,11 +1772,15 @@ extern "C" int dvlp_attention_fwd_ex(int dtype, int mode, int64_t B, int64_t N, 
             }
             const bool small = (int64_t)B * N * (ld > ldo ? ld : ldo) * 2 < (int64_t)0x7fffff00;       // 32-bit byte offsets inside a tensor
             if (g_attn_lean && a.cls_o && small && !(a.abl & 7)) {          // (the fold guarantees nqt == nkt <= 3)
-                const size_t l_ = (size_t)4 * (((nkt + 1) & ~1) * 16 * VLD) * sizeof(bf16); const int items_ = (int)(B * H * F);
-#define SFWD(NT_) hipLaunchKernelGGL((sattn_fwd_kernel<NT_>), dim3((unsigned)cdiv(items_, 4)), block, l_, st, a, items_)
+                const size_t l_ = (size_t)(SATTN_WAVES * nkt * 16 * VLD + 16 * VLD) * sizeof(bf16) + (size_t)SATTN_WAVES * (HD + 2) * sizeof(float);
+                const unsigned chunks = (unsigned)cdiv(F, SATTN_WAVES);
+#define SFWD(NT_) hipLaunchKernelGGL((sattn_fwd_kernel<NT_>), dim3((unsigned)(B * H), chunks), dim3(64 * SATTN_WAVES), l_, st, a)
                 if (nkt == 3) SFWD(3); else if (nkt == 2) SFWD(2); else SFWD(1);
 #undef SFWD
-                done = true;
+                // <= 8 frames: merged inside the kernel; more: the combine launch over the per-frame partials
+                if (chunks > 1) hipLaunchKernelGGL(attn_fwd_cls_combine_kernel, dim3((unsigned)H, (unsigned)B), dim3(64), 0, st, a);
+                if (ext) ext->folded = 1;
+                return dvlp_launch_status();
             }
             else if (nqt == 3 && nkt == 3) MFWD(3, 3, B * H * F, 1);
             else if (nqt == 2 && nkt == 2) MFWD(2, 2, B * H * F, 1);
