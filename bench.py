@@ -275,7 +275,7 @@ def main():
     B, F, R = a.batch, a.frames, a.regions
     cdt = "bfloat16" if a.dtype == "bf16" else "float32"
     model = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
-                           {"model": "", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=cdt)
+                           {"model": "", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False, compute_dtype=cdt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R).items()})
     model.to(dev)
     if a.text_dropout >= 0.0:

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from . import functional as Fn
 from ._lib import DemoVLPHipError
-from .object_transformer import ObjectTransformer
+from .object_transformer import ObjectTransformer, load_clip_pt_weight
 from .text_model import DistilBertEncoder
 
 _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
@@ -35,8 +35,13 @@ def state_dict_data_parallel_fix(load_state_dict, curr_state_dict):
 
 
 class ObjectRelation(nn.Module):
+    """``pretrained_init=True`` (default) is the reference's constructor (model/model.py:29-36): DistilBERT from the local
+    HuggingFace directory ``text_params['model']`` and the object tower from ``pretrained/jx_vit_base_p16_224-80ecf9dd.pth``
+    (``load_clip_pt_weight``, strict=False); either one missing raises, as it does there.  ``pretrained_init=False`` is the explicit
+    opt-out for synthetic runs (tests, ``bench.py``): both towers start from random weights of the same distributions."""
+
     def __init__(self, object_params, text_params, projection_dim=256, load_checkpoint=None, projection="minimal",
-                 load_temporal_fix="zeros", compute_dtype="float32"):
+                 load_temporal_fix="zeros", compute_dtype="float32", pretrained_init=True):
         super().__init__()
         self.text_params = text_params
         self.object_params = object_params
@@ -45,10 +50,13 @@ class ObjectRelation(nn.Module):
             raise NotImplementedError("Huggingface text models require pretrained init.")
         if projection_dim != 256:
             raise NotImplementedError("projection_dim is 256 on this path (model/model.py:65)")
-        self.text_model = DistilBertEncoder.from_pretrained(text_params.get("model"))
+        self.text_model = DistilBertEncoder.from_pretrained(text_params.get("model"), allow_random_init=not pretrained_init)
+        self.text_model.train()                                                                   # model/model.py:30
         self.object_model = ObjectTransformer(input_dim=2054, region_nums=object_params["object_num"], output_dim=256,
                                               time_module=object_params.get("time_module"),
                                               num_frames=object_params["num_frames"])
+        if pretrained_init:
+            load_clip_pt_weight(self.object_model)                                                # model/model.py:31-36
         if projection != "minimal":
             raise NotImplementedError(projection)
         # nn.Sequential(nn.ReLU(), nn.Linear(768, 256)): keep the index so the key is txt_proj.1.*
@@ -172,8 +180,8 @@ class ObjectQARelation(ObjectRelation):
     embeddings with the loader's 0/1 region mask."""
 
     def __init__(self, object_params, text_params, projection_dim=256, load_checkpoint=None, projection="minimal",
-                 load_temporal_fix="bilinear", compute_dtype="float32"):
-        super().__init__(object_params, text_params, projection_dim, None, projection, load_temporal_fix, compute_dtype)
+                 load_temporal_fix="bilinear", compute_dtype="float32", pretrained_init=True):
+        super().__init__(object_params, text_params, projection_dim, None, projection, load_temporal_fix, compute_dtype, pretrained_init)
         from .video_qa_model import BUTDQAHead
         self.head = BUTDQAHead(v_dim=256, q_dim=256, hid_dim=256, out_dim=object_params["num_label"])
         if load_checkpoint not in ["", None]:
@@ -209,8 +217,8 @@ class ObjectMCRelation(ObjectRelation):
     (the reference class is a copy of it; only the trainer that consumes the embeddings differs)."""
 
     def __init__(self, object_params, text_params, projection_dim=256, load_checkpoint=None, projection="minimal",
-                 load_temporal_fix="zeros", compute_dtype="float32"):
-        super().__init__(object_params, text_params, projection_dim, load_checkpoint, projection, load_temporal_fix, compute_dtype)
+                 load_temporal_fix="zeros", compute_dtype="float32", pretrained_init=True):
+        super().__init__(object_params, text_params, projection_dim, load_checkpoint, projection, load_temporal_fix, compute_dtype, pretrained_init)
 
 
 def sim_matrix(a, b, eps=1e-8):

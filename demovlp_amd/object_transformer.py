@@ -6,12 +6,15 @@ the arithmetic runs in hand-written gfx950 kernels (functional.py -> ops.py -> l
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 
 from . import functional as Fn
 
 EMBED, DEPTH, HIDDEN = 768, 12, 3072
+VIT_CHECKPOINT = "pretrained/jx_vit_base_p16_224-80ecf9dd.pth"       # relative to the working directory, as object_transformer.py:480
 
 
 class _Affine(nn.Module):
@@ -24,40 +27,56 @@ class _Affine(nn.Module):
 
 
 class _Linear(nn.Module):
-    def __init__(self, fin, fout, bias=True):
+    """Parameters of an nn.Linear under the reference's names.  ``init='linear'``: torch's nn.Linear default (what every Linear of the
+    reference's tower starts from when num_frames > 1, and object_embedding / pos_embedding / proj always: they are created after
+    ``self.apply(self._init_weights)``, object_transformer.py:364-381); ``init='vit'``: ``_init_weights`` (:384-391: trunc_normal
+    std 0.02, zero bias) -- the blocks when num_frames == 1."""
+
+    def __init__(self, fin, fout, bias=True, init="vit"):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(fout, fin))
         self.bias = nn.Parameter(torch.zeros(fout)) if bias else None
-        nn.init.trunc_normal_(self.weight, std=0.02)
+        self.reset_parameters(init)
+
+    def reset_parameters(self, init="vit"):
+        if init == "vit":
+            nn.init.trunc_normal_(self.weight, std=0.02)
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+        else:
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+            if self.bias is not None:
+                bound = 1.0 / math.sqrt(self.weight.shape[1])
+                nn.init.uniform_(self.bias, -bound, bound)
 
 
 class VarAttention(nn.Module):
-    def __init__(self, dim):
+    def __init__(self, dim, init="vit"):
         super().__init__()
-        self.qkv = _Linear(dim, dim * 3)
-        self.proj = _Linear(dim, dim)
+        self.qkv = _Linear(dim, dim * 3, init=init)
+        self.proj = _Linear(dim, dim, init=init)
 
 
 class Mlp(nn.Module):
-    def __init__(self, dim, hidden):
+    def __init__(self, dim, hidden, init="vit"):
         super().__init__()
-        self.fc1 = _Linear(dim, hidden)
-        self.fc2 = _Linear(hidden, dim)
+        self.fc1 = _Linear(dim, hidden, init=init)
+        self.fc2 = _Linear(hidden, dim, init=init)
 
 
 class SpaceTimeBlock(nn.Module):
     """model/object_transformer.py:199-274 with time_module falsy.  norm3 exists (and never gets a gradient), as in
     the reference, so checkpoints interchange."""
 
-    def __init__(self, dim=EMBED, hidden=HIDDEN, time_module=None):
+    def __init__(self, dim=EMBED, hidden=HIDDEN, time_module=None, init="vit"):
         super().__init__()
         self.time_module = time_module
         self.norm1 = _Affine(dim)
-        self.attn = VarAttention(dim)
+        self.attn = VarAttention(dim, init)
         if time_module == "timeattn":
-            self.timeattn = VarAttention(dim)          # time_init='rand' in the reference (:318): ordinary initialisation
+            self.timeattn = VarAttention(dim, init)    # time_init='rand' in the reference (:318): ordinary initialisation
         self.norm2 = _Affine(dim)
-        self.mlp = Mlp(dim, hidden)
+        self.mlp = Mlp(dim, hidden, init)
         self.norm3 = _Affine(dim)
 
     def forward(self, x, addmask, frames, regions, addmask_t=None, f2b_below=None, f2b_from_above=False):
@@ -89,11 +108,15 @@ class ObjectTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, EMBED))
         self.custom_pos_embed = nn.Parameter(torch.zeros(1, region_nums + 1, EMBED))
         self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, EMBED))
-        self.blocks = nn.ModuleList([SpaceTimeBlock(time_module=self.time_module) for _ in range(DEPTH)])
+        # initial values as the reference leaves them BEFORE load_clip_pt_weight overwrites the blocks (:364-381): with one frame
+        # `self.apply(self._init_weights)` has run over the blocks (trunc_normal 0.02, zero biases); with more frames the blocks keep
+        # nn.Linear's default; the three Linears created after that call keep nn.Linear's default in both cases
+        blk_init = "vit" if num_frames == 1 else "linear"
+        self.blocks = nn.ModuleList([SpaceTimeBlock(time_module=self.time_module, init=blk_init) for _ in range(DEPTH)])
         self.norm = _Affine(EMBED)            # defined and never applied (object_transformer.py:354, 446-452)
-        self.object_embedding = _Linear(self.feat_dim, EMBED)
-        self.pos_embedding = _Linear(input_dim - self.feat_dim, EMBED)
-        self.proj = _Linear(EMBED, output_dim, bias=False)
+        self.object_embedding = _Linear(self.feat_dim, EMBED, init="linear")
+        self.pos_embedding = _Linear(input_dim - self.feat_dim, EMBED, init="linear")
+        self.proj = _Linear(EMBED, output_dim, bias=False, init="linear")
         nn.init.trunc_normal_(self.custom_pos_embed, std=0.02)
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.compute_dtype = torch.float32
@@ -155,3 +178,14 @@ class ObjectTransformer(nn.Module):
         """x [B,F,R,2054], x_mask [B,F,R] (1 = real region) -> (embeddings [B,N,256], additive mask [B,N])."""
         tok, addmask = self.forward_features(x, x_mask)
         return Fn.LinearFn.apply(tok, self.proj.weight, None, None), addmask
+
+
+def load_clip_pt_weight(model, path=VIT_CHECKPOINT):
+    """model/object_transformer.py:470-483: initialise the tower from timm's ViT-B/16 checkpoint, ``strict=False`` -- every
+    ``blocks.N.{norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2}``, ``cls_token`` and ``norm`` tensor matches by name and is loaded;
+    ``pos_embed``, ``patch_embed.*`` and ``head.*`` have no counterpart and are ignored; ``custom_pos_embed``, ``temporal_embed``,
+    ``norm3``, ``object_embedding``, ``pos_embedding``, ``proj`` (and ``timeattn``) keep their initial values.  A missing file raises
+    ``FileNotFoundError`` and a tensor of the wrong shape ``RuntimeError``, as in the reference."""
+    vit_checkpoint = torch.load(path, map_location="cpu")
+    model.load_state_dict(vit_checkpoint, strict=False)
+    return model

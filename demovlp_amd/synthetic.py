@@ -197,6 +197,38 @@ def fill_tensor(name: str, shape) -> np.ndarray:
     return (0.02 * z).astype(np.float32)
 
 
+def vit_checkpoint_schema(blocks=range(12)) -> "dict[str, tuple]":
+    """Name -> shape of timm's ``vit_base_patch16_224`` state_dict (the file ``pretrained/jx_vit_base_p16_224-80ecf9dd.pth`` that
+    ``load_clip_pt_weight`` reads, model/object_transformer.py:470-483), restricted to ``blocks``.  Of these, ``pos_embed``,
+    ``patch_embed.*`` and ``head.*`` have no counterpart in ObjectTransformer (ignored by strict=False)."""
+    D, Hd = 768, 3072
+    s: "dict[str, tuple]" = {"cls_token": (1, 1, D), "pos_embed": (1, 197, D), "patch_embed.proj.weight": (D, 3, 16, 16), "patch_embed.proj.bias": (D,)}
+    for l in blocks:
+        p = f"blocks.{l}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (Hd, D)
+        s[p + "mlp.fc1.bias"] = (Hd,)
+        s[p + "mlp.fc2.weight"] = (D, Hd)
+        s[p + "mlp.fc2.bias"] = (D,)
+    s["norm.weight"] = (D,)
+    s["norm.bias"] = (D,)
+    s["head.weight"] = (1000, D)
+    s["head.bias"] = (1000,)
+    return s
+
+
+def vit_checkpoint(blocks=range(12)) -> "dict[str, np.ndarray]":
+    """A synthetic stand-in for the timm checkpoint: closed-form values keyed ``vit/<name>`` (distinct from every model fill)."""
+    return {k: fill_tensor("vit/" + k, shp) for k, shp in vit_checkpoint_schema(blocks).items()}
+
+
 _FILL_CACHE: "dict[tuple, dict]" = {}
 _FILL_CACHE_MAX = 3          # 614 MB per full-size entry; the test suites rebuild the same two or three models ~100 times (4.3 s of PCG64 each)
 

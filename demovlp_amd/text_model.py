@@ -105,25 +105,40 @@ class DistilBertEncoder(nn.Module):
         return self._drop_state
 
     @classmethod
-    def from_pretrained(cls, path):
-        """Load ``config.json`` + weights from a HuggingFace directory if it exists; otherwise (no network on this box)
-        build the default distilbert-base-uncased shape with random init."""
-        cfg, sd = {}, None
-        if path and os.path.isdir(path):
-            cj = os.path.join(path, "config.json")
-            if os.path.exists(cj):
-                cfg = json.load(open(cj))
-            st = os.path.join(path, "model.safetensors")
-            pb = os.path.join(path, "pytorch_model.bin")
-            if os.path.exists(st):
-                from safetensors.torch import load_file
-                sd = load_file(st)
-            elif os.path.exists(pb):
-                sd = torch.load(pb, map_location="cpu")
+    def from_pretrained(cls, path, allow_random_init=False):
+        """``AutoModel.from_pretrained(text_params['model'])`` (model/model.py:29) for a LOCAL HuggingFace directory: ``config.json``
+        + ``model.safetensors`` or ``pytorch_model.bin``; keys with or without the ``distilbert.`` prefix.  As with HuggingFace, a
+        missing directory, a missing ``config.json`` or missing weights raise ``OSError`` -- nothing is initialised at random behind the
+        caller's back.  ``allow_random_init=True`` (synthetic runs: tests, ``bench.py``, boxes without the checkpoint) builds the
+        default distilbert-base-uncased shape with random weights when ``path`` is empty or absent."""
+        if not path or not os.path.isdir(path):
+            if allow_random_init:
+                return cls(_Config())
+            raise OSError(f"Can't load config for {path!r}: not a local directory with a config.json (this build has no hub access; "
+                          f"pass pretrained_init=False to ObjectRelation for random weights)")
+        cj = os.path.join(path, "config.json")
+        if not os.path.exists(cj):
+            raise OSError(f"Can't load config for {path!r}: {cj} is missing")
+        with open(cj) as fh:
+            cfg = json.load(fh)
+        if cfg.get("model_type", "distilbert") != "distilbert":
+            raise NotImplementedError(f"text model type {cfg.get('model_type')!r}: the kernels implement DistilBERT (every shipped config)")
+        st = os.path.join(path, "model.safetensors")
+        pb = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        elif os.path.exists(pb):
+            sd = torch.load(pb, map_location="cpu")
+        else:
+            raise OSError(f"Error no file named model.safetensors or pytorch_model.bin found in directory {path}.")
         m = cls(_Config(**cfg))
-        if sd is not None:
-            sd = {k[len("distilbert."):] if k.startswith("distilbert.") else k: v for k, v in sd.items()}
-            m.load_state_dict(sd, strict=False)
+        sd = {k[len("distilbert."):] if k.startswith("distilbert.") else k: v for k, v in sd.items()}
+        own = m.state_dict()
+        missing = sorted(k for k in own if k not in sd)
+        if missing:                       # HuggingFace warns "newly initialized"; a half-loaded tower is never what a caller wants here
+            raise OSError(f"checkpoint in {path} lacks {len(missing)} DistilBERT tensors, e.g. {missing[:3]}")
+        m.load_state_dict({k: sd[k] for k in own}, strict=True)          # vocab_projector.* / vocab_transform.* (the MLM head) are ignored, as AutoModel does
         return m
 
     def forward(self, input_ids=None, attention_mask=None, want_relu=False, **_):

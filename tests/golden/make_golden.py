@@ -529,6 +529,46 @@ def golden_benchmark_curve(ref_model, ref_loss):
     print("g12 written")
 
 
+def golden_pretrained_init(ref_model):
+    """G13: what the reference's CONSTRUCTOR leaves in ``object_model`` when the ViT checkpoint is not empty (model/model.py:29-36,
+    model/object_transformer.py:470-483).  A synthetic timm-shaped checkpoint holding blocks 0, 5 and 11 only (so that loaded and
+    untouched tensors both occur inside the blocks) is put where ``load_clip_pt_weight`` reads it; stored per tensor: whether the
+    constructor took it from the file, the crc32 of its bytes if so, else the mean / std of its initial values (init-distribution check)."""
+    import zlib
+    ck = syn.vit_checkpoint(blocks=(0, 5, 11))
+    path = "pretrained/jx_vit_base_p16_224-80ecf9dd.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in ck.items()}, path)
+    out = {}
+    try:
+        for F, R in ((8, 30), (1, 30)):
+            torch.manual_seed(1)
+            m = ref_model.ObjectRelation(
+                object_params={"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": ""},
+                text_params={"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True})
+            sd = m.object_model.state_dict()
+            names, loaded, crc, mean, std = [], [], [], [], []
+            for k, v in sd.items():
+                a = v.detach().numpy()
+                took = k in ck and a.shape == ck[k].shape and np.array_equal(a, ck[k])
+                names.append(k)
+                loaded.append(took)
+                crc.append(zlib.crc32(np.ascontiguousarray(a).tobytes()) if took else 0)
+                mean.append(float(a.astype(np.float64).mean()))
+                std.append(float(a.astype(np.float64).std()))
+            tag = f"F{F}_R{R}_"
+            out[tag + "names"] = np.array(names)
+            out[tag + "loaded"] = np.array(loaded)
+            out[tag + "crc"] = np.array(crc, np.uint32)
+            out[tag + "mean"] = np.array(mean)
+            out[tag + "std"] = np.array(std)
+            out[tag + "unexpected"] = np.array(sorted(k for k in ck if k not in sd))
+            assert m.text_model.training
+            print("g13", tag, "loaded", int(np.sum(loaded)), "of", len(names), "unexpected", out[tag + "unexpected"])
+    finally:
+        torch.save({}, path)
+    np.savez_compressed(os.path.join(HERE, "g13_pretrained_init.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -549,6 +589,8 @@ def main():
             golden_retrieval(ref_model, ref_loss)
         if "g12" in only:
             golden_benchmark_curve(ref_model, ref_loss)
+        if "g13" in only:
+            golden_pretrained_init(ref_model)
         return
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
@@ -563,6 +605,7 @@ def main():
     golden_qa(ref_model, ref_loss, ref_data, scratch)
     golden_retrieval(ref_model, ref_loss)
     golden_benchmark_curve(ref_model, ref_loss)
+    golden_pretrained_init(ref_model)
 
 
 if __name__ == "__main__":

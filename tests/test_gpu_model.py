@@ -19,7 +19,7 @@ DEV = "cuda"
 
 def build(F, R, dtype="float32"):
     m = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
-                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True},
+                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False,
                        compute_dtype=dtype)
     sd = {k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R).items()}
     m.load_state_dict(sd, strict=True)

@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def build(F, R, dtype="float32", time_module=None):
     m = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": time_module},
-                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True},
+                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False,
                        compute_dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R, time_module).items()}, strict=True)
     m.set_text_dropout(0.0)            # the goldens were generated with DistilBertConfig(dropout=0, attention_dropout=0)
@@ -735,7 +735,7 @@ def test_qa_model_vs_reference_golden():
     g = load_golden("g10_qa.npz")
     F, R, B, NL = int(g["F"]), int(g["R"]), int(g["B"]), int(g["num_label"])
     m = ObjectQARelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None, "num_label": NL},
-                         {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True})
+                         {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False)
     sd = syn.fill_state_dict(F, R, None, NL)
     assert set(m.state_dict()) == set(sd)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)

@@ -31,7 +31,7 @@ DEV = "cuda"
 
 def build(F, R, dtype="float32"):
     m = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
-                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True},
+                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False,
                        compute_dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R).items()}, strict=True)
     m.set_text_dropout(0.0)

@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 def _retrieval_model(F, R, sd, dtype):
     m = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
-                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=dtype)
+                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False, compute_dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m.set_text_dropout(0.0)
     return m.to(DEV)

@@ -27,7 +27,7 @@ DEV = "cuda"
 
 def _build(F, R, dtype):
     m = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
-                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=dtype)
+                       {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False, compute_dtype=dtype)
     sd = syn.fill_state_dict(F, R)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m.set_text_dropout(0.0)                                       # the golden was generated with dropout 0

@@ -19,6 +19,7 @@ import demovlp_amd.loss as loss_mod
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = {
     "n_gpu": 8,
+    "pretrained_init": False,      # synthetic runs: the factory fills constructor parameters from top-level keys (parse_config_dist_multi.py:88-92)
     "arch": {"type": "ObjectRelation", "args": {
         "object_params": {"model": "", "input_objects": False, "object_num": 30, "num_frames": 1, "time_module": None},
         "text_params": {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True},
@@ -52,7 +53,7 @@ def test_reference_argument_errors():
         model_mod.ObjectRelation({"object_num": 30, "num_frames": 1, "time_module": None}, {"model": "", "pretrained": False})
     with pytest.raises(NotImplementedError):
         model_mod.ObjectRelation({"object_num": 30, "num_frames": 1, "time_module": None}, {"model": "", "pretrained": True},
-                                 projection="full")
+                                 projection="full", pretrained_init=False)
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -24,7 +24,7 @@ ap.add_argument("--dtype", default="bfloat16")
 a = ap.parse_args()
 F, R, dev = 8, 30, "cuda"
 model = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": None},
-                       {"model": "", "pretrained": True, "input": "text", "two_outputs": True}, compute_dtype=a.dtype)
+                       {"model": "", "pretrained": True, "input": "text", "two_outputs": True}, pretrained_init=False, compute_dtype=a.dtype)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(F, R).items()})
 model.to(dev)
 loss_fn = GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
