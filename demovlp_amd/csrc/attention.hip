@@ -67,10 +67,10 @@ __device__ __forceinline__ void keep4(const uint8_t* p, float scale, float (&m)[
 }
 static int g_attn_abl = 0;
 static int g_attn_lean = 1;        // space-mode bf16, CLS folded: 1 = the round-5 kernels (buffer addressing, swapped output products), 0 = rounds 3-4 (A/B, tests)
-extern "C" int dvlp_dev_attention_lean(int on) { g_attn_lean = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_attention_lean(int on) { g_attn_lean = on; return DVLP_OK; }
 static int g_attn_merged = 1;      // space-mode bf16 backward: 1 = one-pass form, 0 = the three-launch form (A/B, tests)
-extern "C" int dvlp_dev_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
-extern "C" int dvlp_dev_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_attention_bwd_variant(int merged) { g_attn_merged = merged; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_attention_ablate(int bits) { g_attn_abl = bits; return DVLP_OK; }
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
@@ -1730,7 +1730,7 @@ float* dvlp_rd_reserve_push(int64_t P, int64_t C, float* out);      // norm.hip:
 // (dvlp_attn_ext::colsum: the backward (mode 0) also queues the column sums of dq | dk | dv ([3*H*64] fp32: the packed qkv bias gradient)
 //  when it can -- bf16 one-pass form with forward statistics, deferred reductions enabled -- and says so in colsum_fused)
 static int g_attn_fold = 1;        // space-mode bf16: 1 = CLS query folded into the frame waves when the caller passes workspaces, 0 = separate launches (A/B, tests)
-extern "C" int dvlp_dev_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_attention_cls_fold(int on) { g_attn_fold = on; return DVLP_OK; }
 
 // `workspace` (B*H*F*66 floats) + `cls_stats` (B*H*4 floats), both optional: space mode, bf16 -- the CLS query is folded into the
 // frame waves and its global softmax statistics are kept in `cls_stats` for dvlp_attention_bwd.  ext->folded says whether that

@@ -13,6 +13,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { DVLP_F32 = 0, DVLP_BF16 = 1 };
 enum { DVLP_OK = 0, DVLP_ERR_DTYPE = -1, DVLP_ERR_SHAPE = -2, DVLP_ERR_LAUNCH = -3, DVLP_ERR_UNSUPPORTED = -4 };
 
+// Developer switches (dvlp_dev_*: A/B measurements, timing ablations, forced code paths; include/demovlp_hip_dev.h).  Only the
+// -DDVLP_DEV build (libdemovlp_hip_dev.so) exports their setters; in the product library a setter is an unreferenced internal
+// function, nothing can write the switch and the compiler folds it to its default.
+#ifdef DVLP_DEV
+#define DVLP_DEV_API extern "C"
+#else
+#define DVLP_DEV_API [[maybe_unused]] static
+#endif
+
 // epilogue flags of dvlp_gemm (keep in sync with include/demovlp_hip.h)
 enum {
     EPI_GELU = 1,       // aux <- pre-activation, C <- gelu_erf(v)

@@ -1437,25 +1437,25 @@ extern "C" const char* dvlp_last_error_string() { return hipGetErrorString((hipE
 
 // A/B switch between the LDS-DMA kernel (default) and the register-staged one (tools/gemm_bench.py --variant)
 static int g_ablate = 0;         // tools/gemm_bench.py --ablate: 1 skip LDS-DMA issue, 2 skip LDS fragment reads, 4 skip MFMAs (TIMING ONLY)
-extern "C" int dvlp_dev_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_ablate(int bits) { g_ablate = bits; return DVLP_OK; }
 static bool g_use_glds = true;
 static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: measured no faster on this path's shapes), 1: heuristic, 2: always
-extern "C" int dvlp_dev_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
 static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile patches pinned to XCDs (operand panels shared through L2), 0 = per-problem tile order
-extern "C" int dvlp_dev_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
-extern "C" int dvlp_dev_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
 static int g_p8_persist = 1;     // persistent form of the 256-row kernel on multi-round outputs: 0 off, 1 on (default; A/B: tools/p8p_bench.py)
-extern "C" int dvlp_dev_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
 static int g_p8_short = 1;       // 224-row tiles of the 256-row kernel: 0 never, 1 where they save CU-rounds (default), 2 whenever allowed
-extern "C" int dvlp_dev_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
 static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
-extern "C" int dvlp_dev_gemm_force_split(int s) { g_force_split = s; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_force_split(int s) { g_force_split = s; return DVLP_OK; }
 static int g_wgrad_split = 0;    // grouped weight gradients: 0 = automatic uniform K split, > 0 = forced
-extern "C" int dvlp_dev_wgrad_group_split(int s) { g_wgrad_split = s; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_wgrad_group_split(int s) { g_wgrad_split = s; return DVLP_OK; }
 static int64_t g_splitk_target = 768;     // workgroups a split-K launch aims for (tools/gemm_bench.py --splitk-target)
-extern "C" int dvlp_dev_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
-extern "C" int dvlp_dev_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_splitk_target(int64_t n) { g_splitk_target = n > 0 ? n : 768; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_gemm_variant(int use_lds_dma) { g_use_glds = use_lds_dma != 0; return DVLP_OK; }
 
 // caller-provided scratch for split-K slabs (dvlp_set_workspace); nullptr disables splitting
 // One scratch buffer per stream (two GEMMs in flight on different streams must not share slabs); stream 0 entry is the

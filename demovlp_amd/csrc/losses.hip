@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
 }
 
 static int g_loss_mfma = 1;
-extern "C" int dvlp_dev_loss_mfma(int on) { g_loss_mfma = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_loss_mfma(int on) { g_loss_mfma = on; return DVLP_OK; }
 // sim / dsim: fp32 [B*B] each.  stages (bitmask): 1 = sim_matrix forward (gt, go -> sim); 2 = losses from sim / xs, with
 // dsim = d global / d sim and dxs = d local / d xs; 4 = sim_matrix backward (dsim -> dgt, dgo).  7 = everything in one launch.
 extern "C" int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
 }
 
 static int g_ln_wide = 1;        // bf16 D = 768 forward: 1 = half-wave-per-row kernel with 16-byte accesses, 0 = the generic kernel (A/B, tests)
-extern "C" int dvlp_dev_layernorm_wide(int on) { g_ln_wide = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_layernorm_wide(int on) { g_ln_wide = on; return DVLP_OK; }
 extern "C" int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps,
                                   void* y, void* y_relu, float* mean, float* rstd, void* stream) {
     dvlp_clear_status();

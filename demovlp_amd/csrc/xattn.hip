@@ -19,7 +19,9 @@
 #include <cstdlib>
 
 constexpr int XD = 256;   // projection_dim (model/model.py:65)
-constexpr int64_t XSIDE_SLAB_BYTES = 64ll << 20;
+// fp32 split-K slabs of the side stream's backward products (dQhat_j: [Wp x d] and [Wp x Wp] outputs, batch Bj): room for a 16-way split,
+// at most 64 MB -- a function of the shape alone, so that dvlp_xattn_workspace_bytes, the forward and the backward agree on the layout
+static inline int64_t xside_slab_bytes(int64_t Bj, int64_t Wp) { const int64_t want = 16 * Wp * 256 * 4 * Bj; return want < (64ll << 20) ? want : (64ll << 20); }
 extern "C" int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes);
 
 extern "C" int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
@@ -40,14 +42,14 @@ struct XLayout {
 };
 static size_t pair_lds(int64_t G, int64_t W, int bwd);
 static bool g_force_general = false;
-extern "C" int dvlp_dev_xattn_force_general(int on) { g_force_general = on != 0; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_force_general(int on) { g_force_general = on != 0; return DVLP_OK; }
 // fused per-pair kernels (xfused.hip): bf16, G <= 288, W <= 112
 bool dvlp_xfused_ok(int64_t G, int64_t W);
 int64_t dvlp_xfused_workspace_bytes(int64_t Bi, int64_t Bj, int64_t G, int64_t W);
 int dvlp_xfused_fwd(int64_t Bi, int64_t Bj, int64_t G, int64_t W, const void* Craw, const void* Qraw, const float* mimg, const float* mcap,
                     float lam, int gate, float* scores, void* workspace, hipStream_t st);
 static int g_fused = 1;          // 1 (default): use the fused kernels where they apply; 0: always the multi-kernel path (A/B, tests)
-extern "C" int dvlp_dev_xattn_fused_mode(int mode) { g_fused = mode; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_fused_mode(int mode) { g_fused = mode; return DVLP_OK; }
 static bool x_fused(int dtype, int64_t G, int64_t W, int bwd) {
     return g_fused && !g_force_general && dtype == DVLP_BF16 && !bwd && dvlp_xfused_ok(G, W);
 }
@@ -61,10 +63,10 @@ static bool x_general(int64_t G, int64_t W) { return g_force_general || pair_lds
 // Replaces two [.,d]-wide batched products, the wc2 half of the cosine passes and two backward products by one [Bi*G, W] x [W, W]
 // product per caption, two passes over [B,B,G,W] tiles that exist anyway, and W x W products.
 static int g_gram = getenv("DVLP_XATTN_NO_GRAM") ? 0 : 1;
-extern "C" int dvlp_dev_xattn_gram(int on) { g_gram = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_gram(int on) { g_gram = on; return DVLP_OK; }
 static int g_xbwd_packed_fwd();       // (defined below: the Gram form needs the bf16 backward kernel)
 static int g_pairg = 1;          // bf16 backward: dP1 columns in xperm_g order (A/B, tests)
-extern "C" int dvlp_dev_xattn_pair_regions(int on) { g_pairg = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_pair_regions(int on) { g_pairg = on; return DVLP_OK; }
 static bool x_pairg(int dtype, int64_t G, int64_t W) { return g_pairg && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G >= 128; }
 static bool x_gram(int dtype, int64_t G, int64_t W) { return g_gram && g_xbwd_packed_fwd() && dtype == DVLP_BF16 && !x_general(G, W) && G <= 64 * 6; }
 
@@ -100,7 +102,7 @@ static XLayout xlayout(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, 
         L.off_dirq = take(Bj * W * XD * 4);
         // split-K slabs of the products issued on the library's own side stream (parallel halves): that stream must never fall back to the
         // caller's default-stream GEMM workspace, which the main stream's split products may be using at the same moment
-        L.off_sideslab = take(XSIDE_SLAB_BYTES);
+        L.off_sideslab = take(xside_slab_bytes(Bj, L.Wp));
     }
     if (x_general(G, W)) {       // general-G path: reciprocal norms and partial dot products
         L.off_rinv = take(Bi * Bj * G * 4);
@@ -1243,10 +1245,10 @@ static void launch_pair_w(bool bwd, int nkw, dim3 grid, size_t lds, hipStream_t 
 #undef XLAUNCH
 }
 static int g_xstop = 0;
-extern "C" int dvlp_dev_xattn_bwd_stop(int stage) { g_xstop = stage; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_bwd_stop(int stage) { g_xstop = stage; return DVLP_OK; }
 static int g_xbwd_packed = 1;    // bf16 backward: 1 = xsoftmax_bwd_bf16_kernel, 0 = the generic kernel (A/B, tests)
 static int g_xbwd_packed_fwd() { return g_xbwd_packed; }
-extern "C" int dvlp_dev_xattn_bwd_variant(int packed) { g_xbwd_packed = packed; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_bwd_variant(int packed) { g_xbwd_packed = packed; return DVLP_OK; }
 static size_t pair_lds_bf16_bwd(int64_t G, int64_t W) {
     const int64_t Wq = W | 1;
     return (size_t)(G * Wq + G + W + 8 * W + G + W + 16 * G + 32 * 32 * cdiv(rup(W, 8), 32)) * sizeof(float);
@@ -1289,15 +1291,18 @@ static void launch_pair(bool bwd, int nkg, int nkw, dim3 grid, size_t lds, hipSt
 // beside the image->text half (fork / join by events -- legal inside a hipGraph capture), so the pair fills the memory system.
 // ON by default since round 5 (dvlp_dev_xattn_parallel_halves(0) / DVLP_XATTN_PARALLEL=0 switch it off): -0.2 ms on the B = 64 backward alone
 // (round 3) and -0.13 ms in the replayed step, three alternating runs out of three (18.34 / 18.27 / 18.22 -> 18.18 / 18.11 / 18.15 ms: by
-// then the text tower's stream is idle, so the second half has the chip's spare CUs to itself).  The library's own side stream has no split-K
-// workspace registered (ops.py registers them per torch stream), so its products run unsplit: no slab is shared between the halves.
+// then the text tower's stream is idle, so the second half has the chip's spare CUs to itself).  The side stream's split-K products use a
+// slab region of THEIR OWN inside the caller's workspace (XLayout::off_sideslab), registered under the side stream's key for the length
+// of a fork and erased at the join -- a lookup for that stream never reaches the default-stream slabs the main stream's products write.
+// Per call, bit 1 of `gate` (DVLP_XATTN_ONE_STREAM) keeps everything on the caller's stream (bench.py's per-launch timing pass).
 static int g_xpar = (getenv("DVLP_XATTN_PARALLEL") && atoi(getenv("DVLP_XATTN_PARALLEL")) == 0) ? 0 : 1;
-extern "C" int dvlp_dev_xattn_parallel_halves(int on) { g_xpar = on; return DVLP_OK; }
+DVLP_DEV_API int dvlp_dev_xattn_parallel_halves(int on) { g_xpar = on; return DVLP_OK; }
 struct XFork {
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    bool serial = false;                  // this call asked for one stream (gate bit 1)
     bool ok() {
-        if (!g_xpar) return false;
+        if (!g_xpar || serial) return false;
         if (!side) {
             if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
             (void)hipEventCreateWithFlags(&fork, hipEventDisableTiming);
@@ -1320,6 +1325,7 @@ struct XFork {
         if (second == st) return;
         (void)hipEventRecord(join, second);
         (void)hipStreamWaitEvent(st, join, 0);
+        (void)dvlp_set_workspace_stream((void*)side, nullptr, 0);     // nothing is enqueued there until the next fork registers its own region
     }
 };
 static thread_local XFork t_xfork;
@@ -1330,6 +1336,8 @@ extern "C" int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     dvlp_clear_status();
     if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
+    t_xfork.serial = (gate & 2) != 0;       // DVLP_XATTN_ONE_STREAM
+    gate &= 1;
     if (x_fused(dtype, G, W, bwd)) {
         dvlp_xfused_fwd(Bi, Bj, G, W, Craw, Qraw, mimg, mcap, lam, gate, scores, workspace, (hipStream_t)stream);
         return dvlp_launch_status();
@@ -1413,6 +1421,8 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
     dvlp_clear_status();
     if (d != XD || Bi <= 0 || Bj <= 0 || G <= 0 || W <= 0 || W > 32 * XMAX_NKW) return DVLP_ERR_SHAPE;
     if (dtype != DVLP_F32 && dtype != DVLP_BF16) return DVLP_ERR_DTYPE;
+    t_xfork.serial = (gate & 2) != 0;       // DVLP_XATTN_ONE_STREAM
+    gate &= 1;
     const bool general = x_general(G, W);
     if (general && (W > 128 || (size_t)G * XWS * 3 * sizeof(float) > 150 * 1024)) return DVLP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -1478,7 +1488,7 @@ extern "C" int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int6
             hipLaunchKernelGGL(xg_final_kernel<bf16>, gB, b256, lds3, st, ga); }
     }
     // dChat_i [G x d] = P1[i]^T [G x Bj*Wp] . dwc[i] [Bj*Wp x d]  +  dSraw[i] [G x Bj*Wp] . Qhat [Bj*Wp x d]
-    s2 = t_xfork.begin(st, ws + L.off_sideslab, XSIDE_SLAB_BYTES);
+    s2 = t_xfork.begin(st, ws + L.off_sideslab, xside_slab_bytes(Bj, Wp));
     XG(dtype, 1, 1, G, XD, Bj * Wp, P1, Gp, wc, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, Bi, Bj * Wp * Gp, Bj * Wp * XD,
        G * XD, 0, 0, stream);
     XG(dtype, 0, 1, G, XD, Bj * Wp, S, Bj * Wp, qhat, XD, dchat, XD, nullptr, nullptr, 0, nullptr, 0, EPI_ACCUM, 1.f, Bi, G * Bj * Wp, 0,

@@ -478,7 +478,7 @@ static FusedLayout fused_layout(int64_t Bi, int64_t Bj, int64_t G, int64_t W) {
 }
 
 static int g_xf_stop = 0;
-extern "C" int dvlp_dev_xfused_ablate(int stop) { g_xf_stop = stop; return 0; }
+DVLP_DEV_API int dvlp_dev_xfused_ablate(int stop) { g_xf_stop = stop; return 0; }
 
 bool dvlp_xfused_ok(int64_t G, int64_t W) {
     if (G < 1 || W < 1 || W > 16 * FW_MAXB || G > 16 * 8 * FG_SLOTS) return false;

@@ -143,6 +143,21 @@ def ensure_gemm_workspace(device, mbytes=160):
     return t
 
 
+@_lib.on_library_switch
+def _drop_library_registrations():
+    """Another build of the library is about to become the active one (tests / tools: _lib.use_dev_library): whatever this module
+    registered with the current one -- split-K scratch per stream, colsum counters, the deferred-reduction queue -- is flushed and dropped;
+    it is registered anew, lazily, with whichever library the next call goes to."""
+    if _DEFER:
+        torch.cuda.synchronize()
+        disable_deferred_reductions()
+    for key in list(_GEMM_WS):
+        if key[0] != "alias":
+            call("dvlp_set_workspace_stream", ctypes.c_void_p(key[1]), None, 0)
+    _GEMM_WS.clear()
+    _COLSUM_CNT.clear()
+
+
 _SIDE = {}
 
 
@@ -560,6 +575,14 @@ def cast(src, dtype, out=None):
 # ----------------------------------------------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------------------------------------------
+XATTN_ONE_STREAM = False      # per-call option of dvlp_xattn_fwd / _bwd (gate bit 1): keep the local loss' two halves on the caller's stream
+                              # (bench.py sets it around its per-launch timing pass; the default lets the library fork its side stream)
+
+
+def _gate_bits(gate):
+    return (1 if gate else 0) | (2 if XATTN_ONE_STREAM else 0)
+
+
 def xattn_fwd(C, Q, m_img, m_cap, lam, gate, need_bwd):
     """C [Bi,G,256], Q [Bj,W,256] (compute dtype), additive fp32 masks -> scores fp32 [Bi,Bj], workspace."""
     Bi, G, d = C.shape
@@ -567,7 +590,7 @@ def xattn_fwd(C, Q, m_img, m_cap, lam, gate, need_bwd):
     nbytes = call("dvlp_xattn_workspace_bytes", dt(C), Bi, Bj, G, W, int(need_bwd))
     ws = torch.empty(int(nbytes), device=C.device, dtype=torch.uint8)
     scores = torch.empty((Bi, Bj), device=C.device, dtype=torch.float32)
-    call("dvlp_xattn_fwd", dt(C), Bi, Bj, G, W, d, p(C), p(Q), p(m_img), p(m_cap), float(lam), int(gate), p(scores), p(ws),
+    call("dvlp_xattn_fwd", dt(C), Bi, Bj, G, W, d, p(C), p(Q), p(m_img), p(m_cap), float(lam), _gate_bits(gate), p(scores), p(ws),
          int(need_bwd), stream())
     return scores, ws
 
@@ -576,7 +599,7 @@ def xattn_bwd(C, Q, m_img, m_cap, lam, gate, dscores, ws):
     Bi, G, d = C.shape
     Bj, W, _ = Q.shape
     dC, dQ = torch.empty_like(C), torch.empty_like(Q)
-    call("dvlp_xattn_bwd", dt(C), Bi, Bj, G, W, d, p(C), p(Q), p(m_img), p(m_cap), float(lam), int(gate), p(dscores), p(ws),
+    call("dvlp_xattn_bwd", dt(C), Bi, Bj, G, W, d, p(C), p(Q), p(m_img), p(m_cap), float(lam), _gate_bits(gate), p(dscores), p(ws),
          p(dC), p(dQ), stream())
     return dC, dQ
 

@@ -12,6 +12,8 @@
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -538,6 +540,7 @@ class GraphedTrainStep:
         if exchange not in ("all_reduce", "rs_ag"):
             raise ValueError("exchange must be 'all_reduce' or 'rs_ag'")
         self.exchange = exchange
+        self.exchange_used, self._warned = set(), False       # the forms actually taken (bench.py reports them), one warning on an emulated one
         self.grad_dtype, self.time_exchange, self._xev, self._stage = grad_dtype, bool(time_exchange), [], None
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.warmup, self.calls = max(1, warmup), 0
@@ -674,9 +677,22 @@ class GraphedTrainStep:
         if not pieces:
             return
         half = self.grad_dtype == "bfloat16"
+        # exchange='rs_ag': every bucket's prefix that divides by the world size goes as reduce-scatter + all-gather, the < world elements
+        # left over (world sizes that do not divide the 64-element bucket alignment: 3, 6, ...) as a small all-reduce -- the form taken no
+        # longer depends on the bucket boundaries.  NCCL / RCCL run the two collectives natively and in place; other backends (gloo: the
+        # CPU and two-ranks-on-one-GPU tests) take `_rs_ag_emulated`, which walks the same shard views in the same order.
+        direct = self.exchange == "rs_ag"
+        native = direct and dist.get_backend(self.group) == "nccl"
+        self.exchange_used.add("rs_ag" if native else "rs_ag (emulated: all_reduce + all_gather)" if direct else "all_reduce")
+        if direct and not native and not self._warned:
+            self._warned = True
+            warnings.warn("GraphedTrainStep(exchange='rs_ag'): backend %r has no reduce_scatter_tensor; the shard walk is emulated with all_reduce + "
+                          "all_gather (same result, no link-level benefit)" % dist.get_backend(self.group))
         if not g.is_cuda:
             for lo, hi in pieces:
-                if half:
+                if direct:
+                    self._rs_ag_host(g, lo, hi, half)
+                elif half:
                     h16 = g[lo:hi].to(torch.bfloat16)
                     dist.all_reduce(h16, op=dist.ReduceOp.SUM, group=self.group)
                     g[lo:hi].copy_(h16)
@@ -690,7 +706,6 @@ class GraphedTrainStep:
             self._stage = torch.empty(a.total, device=g.device, dtype=torch.bfloat16)      # one slot per arena element: buckets never share staging
         self._comm.wait_stream(torch.cuda.current_stream())
         ev = None
-        direct = self.exchange == "rs_ag" and dist.get_backend(self.group) == "nccl" and all((hi - lo) % self.world == 0 for lo, hi in pieces)
         with torch.cuda.stream(self._comm):
             if self.time_exchange:
                 # bytes per element that cross the links, up to the (world - 1) / world factor: all-reduce 2 x (4 | 2), scatter 4 + gather (4 | 2)
@@ -703,33 +718,92 @@ class GraphedTrainStep:
                 r = dist.get_rank(self.group)
                 handles = []
                 for lo, hi in pieces:
-                    sh = (hi - lo) // self.world
-                    mine = g[lo + r * sh: lo + (r + 1) * sh]
-                    hrs = dist.reduce_scatter_tensor(mine, g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    if half:
-                        hrs.wait()                                                      # the cast below runs on THIS stream, not on the collective's
-                        mine16 = self._stage[lo + r * sh: lo + (r + 1) * sh]
-                        ops.cast(mine, torch.bfloat16, out=mine16)                      # the owned shard's fp32 sum, rounded once
-                        handles.append(dist.all_gather_into_tensor(self._stage[lo:hi], mine16, group=self.group, async_op=True))
-                    else:
-                        handles.append(dist.all_gather_into_tensor(g[lo:hi], mine, group=self.group, async_op=True))
+                    mid, sh = self.shard_split(lo, hi, self.world)
+                    hs = []
+                    if sh:
+                        mine = g[lo + r * sh: lo + (r + 1) * sh]
+                        if native:
+                            hrs = dist.reduce_scatter_tensor(mine, g[lo:mid], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        else:
+                            hrs = self._reduce_scatter_emulated(mine, g[lo:mid], r, sh)
+                        if half:
+                            hrs.wait()                                                  # the cast below runs on THIS stream, not on the collective's
+                            mine16 = self._stage[lo + r * sh: lo + (r + 1) * sh]
+                            ops.cast(mine, torch.bfloat16, out=mine16)                  # the owned shard's fp32 sum, rounded once
+                            hs.append(dist.all_gather_into_tensor(self._stage[lo:mid], mine16, group=self.group, async_op=True))
+                        else:
+                            hs.append(dist.all_gather_into_tensor(g[lo:mid], mine, group=self.group, async_op=True))
+                    if mid < hi:                                                        # the remainder: fewer than `world` elements
+                        if half:
+                            ops.cast(g[mid:hi], torch.bfloat16, out=self._stage[mid:hi])
+                            hs.append(dist.all_reduce(self._stage[mid:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                        else:
+                            hs.append(dist.all_reduce(g[mid:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    handles.append(hs)
             elif half:
                 for lo, hi in pieces:
                     ops.cast(g[lo:hi], torch.bfloat16, out=self._stage[lo:hi])
-                handles = [dist.all_reduce(self._stage[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in pieces]
+                handles = [[dist.all_reduce(self._stage[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)] for lo, hi in pieces]
             else:
-                handles = [dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in pieces]
+                handles = [[dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)] for lo, hi in pieces]
             if ev is not None:
-                for h in handles:
-                    h.wait()
+                for hs in handles:
+                    for h in hs:
+                        h.wait()
                 ev[1].record()
                 self._xev.append(ev + (piece,))
         with torch.cuda.stream(self._optst):
-            for h, (lo, hi) in zip(handles, pieces):
-                h.wait()                                      # this stream waits for that collective only
+            for hs, (lo, hi) in zip(handles, pieces):
+                for h in hs:
+                    h.wait()                                  # this stream waits for that bucket's collectives only
                 if half:
                     ops.cast(self._stage[lo:hi], torch.float32, out=g[lo:hi])
                 ops.adamw_range_dev(a.flat_p, g, self.opt.m, self.opt.v, self.opt._hyper, a.flat_s, lo, hi)
+
+    @staticmethod
+    def shard_split(lo, hi, world):
+        """(mid, shard): [lo, mid) is the prefix of the bucket that divides by ``world`` (rank r owns [lo + r shard, lo + (r + 1) shard)),
+        [mid, hi) the remainder that goes as a plain all-reduce."""
+        sh = (hi - lo) // world
+        return lo + sh * world, sh
+
+    def _reduce_scatter_emulated(self, mine, whole, r, sh):
+        """Backends without reduce_scatter_tensor: the sum of ``whole`` over the ranks, of which only this rank's shard is kept (the other
+        shards of ``whole`` are left as the native in-place form leaves them: not to be read before the gather)."""
+        tmp = whole.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+        mine.copy_(tmp[r * sh:(r + 1) * sh])
+        whole[:r * sh].fill_(float("nan"))                    # poison what the gather must overwrite: a wrong shard offset shows up as NaN
+        whole[(r + 1) * sh:].fill_(float("nan"))
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
+
+    def _rs_ag_host(self, g, lo, hi, half):
+        """The rs_ag walk on host tensors (gloo, CPU tests): same shard views and order as the device path."""
+        r = dist.get_rank(self.group)
+        mid, sh = self.shard_split(lo, hi, self.world)
+        if sh:
+            mine = g[lo + r * sh: lo + (r + 1) * sh]
+            self._reduce_scatter_emulated(mine, g[lo:mid], r, sh)
+            if half:
+                mine16 = mine.to(torch.bfloat16)
+                out16 = torch.empty(mid - lo, dtype=torch.bfloat16)
+                dist.all_gather_into_tensor(out16, mine16, group=self.group)
+                g[lo:mid].copy_(out16)
+            else:
+                out = torch.empty(mid - lo, dtype=g.dtype)
+                dist.all_gather_into_tensor(out, mine.clone(), group=self.group)
+                g[lo:mid].copy_(out)
+        if mid < hi:
+            if half:
+                h16 = g[mid:hi].to(torch.bfloat16)
+                dist.all_reduce(h16, op=dist.ReduceOp.SUM, group=self.group)
+                g[mid:hi].copy_(h16)
+            else:
+                dist.all_reduce(g[mid:hi], op=dist.ReduceOp.SUM, group=self.group)
 
     def exchange_times(self):
         """[(milliseconds, bytes, piece)] per exchanged piece since the last call, in issue order (``time_exchange=True``): the time the

@@ -23,10 +23,10 @@ extern "C" {
 
 enum { DVLP_F32 = 0, DVLP_BF16 = 1 };
 enum { DVLP_OK = 0, DVLP_ERR_DTYPE = -1, DVLP_ERR_SHAPE = -2, DVLP_ERR_LAUNCH = -3, DVLP_ERR_UNSUPPORTED = -4 };
-/* ---- Naming: entry points called `dvlp_dev_*` are DEVELOPER switches (A/B measurements, timing ablations, tests that force a code path).
- *      They set process-global state, are not part of the drop-in surface, and no product code calls them; every other entry point is
- *      stateless apart from caller-registered scratch (dvlp_set_workspace*, dvlp_reduce_*) -- optional per-call extras travel in the
- *      `dvlp_*_ext` structs of the `*_ex` calls, never through "next call" setters. ---- */
+/* ---- Every entry point here is stateless apart from caller-registered scratch (dvlp_set_workspace*, dvlp_reduce_*); optional per-call
+ *      extras travel in the `dvlp_*_ext` structs of the `*_ex` calls, never through "next call" setters.  The developer switches
+ *      (`dvlp_dev_*`: A/B measurements, timing ablations, forced code paths) are NOT in this library: they exist only in the -DDVLP_DEV
+ *      build (libdemovlp_hip_dev.so, declared in demovlp_hip_dev.h); here each of them is a compile-time constant at its default. ---- */
 /* dvlp_gemm epilogue flags */
 enum { DVLP_EPI_GELU = 1, DVLP_EPI_GELU_BWD = 2, DVLP_EPI_RELU_BWD = 4, DVLP_EPI_ACCUM = 8, DVLP_EPI_LEAKY = 16,
        DVLP_EPI_OUT_F32 = 32 /* C is fp32 whatever the compute dtype (weight gradients) */ };
@@ -51,11 +51,6 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
    host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
-/* K split of dvlp_gemm's bf16 kernels: 0 (default) = automatic, > 0 = forced -- for A/B measurements (tools/gemm_sweep.py) */
-int dvlp_dev_gemm_force_split(int s);
-/* K split of the grouped weight-gradient launch: 0 (default) = automatic (the same split for every problem), > 0 = forced -- for
-   A/B measurements (tools/wgrad_bench.py) */
-int dvlp_dev_wgrad_group_split(int s);
 /* dvlp_gemm with optional extras, handed to the call that consumes them (NULL = none).  `colsum`: fp32 dst[N] = column sums of the stored
    output C -- e.g. the bias gradient of the Linear whose output gradient this product is (batch 1, not for fp32 outputs).  Fused into the
    256-row kernel's epilogue through the deferred-reduction queue where possible (final after dvlp_reduce_flush; colsum_fused = 1),
@@ -67,27 +62,6 @@ typedef struct dvlp_gemm_ext {
 int dvlp_gemm_ex(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                  int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres, void* aux, int64_t ldaux,
                  int flags, float alpha, dvlp_gemm_ext* ext, void* stream);
-/* 1 (default): LDS-DMA (global_load_lds) bf16 kernel; 0: register-staged bf16 kernel -- for A/B measurements */
-int dvlp_dev_gemm_variant(int use_lds_dma);
-/* TIMING-ONLY ablation of the LDS-DMA kernel's K loop (1 no DMA, 2 no fragment reads, 4 no MFMA); 0 in production */
-int dvlp_dev_gemm_ablate(int bits);
-/* 256 x 128 tile of the LDS-DMA kernel: 0 never, 1 heuristic (default), 2 always -- for A/B measurements */
-int dvlp_dev_gemm_wide_mode(int mode);
-/* 256 x 256 ping-pong kernel (8 waves, counted-vmcnt LDS-DMA prefetch): 0 never, 1 where the grid suits it, 2 whenever the
-   operands allow -- for A/B measurements and tests */
-int dvlp_dev_gemm_p8_mode(int mode);
-/* tile height of that kernel: 224-row tiles (the upper half of a tile 96 rows instead of 128) where they fill the CUs' rounds better than
-   256-row ones -- 0 never, 1 (default) where rounds x rows is smaller, 2 whenever the operands allow; for A/B measurements and tests */
-int dvlp_dev_gemm_p8_short_tiles(int mode);
-/* persistent form of that kernel on outputs of more than one round of tiles (one workgroup per CU walks its tiles; the next tile's first
-   units are staged by the previous tile's last phases, the epilogue's stores are not waited for): 0 (default) off, 1 on -- for A/B
-   measurements (tools/p8p_bench.py) and tests */
-int dvlp_dev_gemm_p8_persistent(int mode);
-/* grouped weight gradients: 1 (default) blocks are dealt to the XCDs as 3 x 3 tile patches of one K slice, so a patch's operand panels are
-   fetched into that XCD's L2 once; 0: per-problem tile order -- for A/B measurements */
-int dvlp_dev_wgrad_group_patches(int on);
-/* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
-int dvlp_dev_gemm_splitk_target(int64_t n);
 /* scratch for split-K partial sums (weight-gradient GEMMs); caller-owned device memory, NULL disables splitting */
 int dvlp_set_workspace(void* ptr, int64_t bytes);
 /* same, for one stream only (GEMMs running concurrently on two streams need separate slabs) */
@@ -96,19 +70,9 @@ int dvlp_set_workspace_stream(void* stream, void* ptr, int64_t bytes);
 int dvlp_prof_enable(int on);
 int dvlp_prof_collect(double* total_ms, double* total_flops, int64_t* count);
 
-/* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the
-   three-launch form -- for A/B measurements and tests. */
-int dvlp_dev_attention_bwd_variant(int merged);
-/* space-mode bf16 with the CLS query folded: 1 (default) the round-5 kernels, 0 the round 3-4 ones -- for A/B measurements and tests */
-int dvlp_dev_attention_lean(int on);
-/* TIMING-ONLY ablation of the MFMA attention kernels (backward, round 3-4 form: 1 no stores, 2 no exp, 4 stop after the softmax; forward,
-   round-5 form: 8 loads and stores only -- what the access shape alone costs); 0 in production */
-int dvlp_dev_attention_ablate(int bits);
 /* ---- LayerNorm: norm1/norm2 (object_transformer.py:261,271, eps 1e-6) and DistilBERT's post-LNs (eps 1e-12) ---- */
 int dvlp_layernorm_fwd(int dtype, int64_t M, int64_t D, const void* x, const float* gamma, const float* beta, float eps, void* y,
                        void* y_relu, float* mean, float* rstd, void* stream);
-/* bf16, D = 768: 1 (default) half a wave per row with 16-byte accesses, 0 the generic row-per-wave kernel -- for A/B measurements */
-int dvlp_dev_layernorm_wide(int on);
 int64_t dvlp_layernorm_bwd_blocks(int64_t M);
 /* dx_colsum (optional): fp32 [D] <- column sums of dx, i.e. the bias gradient of the Linear that dx feeds (nn.Linear backward
    after the LayerNorm's); produced by the same kernel on the deferred path, by a dvlp_colsum pass otherwise */
@@ -144,8 +108,6 @@ int dvlp_attention_bwd(int dtype, int mode, int64_t B, int64_t N, int64_t H, int
                        const void* v, int64_t ld, const float* addmask, const void* dout, int64_t ldo, void* dq, void* dk, void* dv,
                        int64_t ldd, float* workspace, float scale, const void* fwd_out, int64_t ld_fwd_out, const float* cls_stats,
                        void* stream);
-/* 1 (default): fold the CLS query where workspaces are given; 0: separate CLS launches -- for A/B measurements and tests */
-int dvlp_dev_attention_cls_fold(int on);
 /* The same two calls with optional extras, handed to the call that consumes them (ext may be NULL):
      keep / keepT / keep_scale  (mode 1) dropout of the attention probabilities: keep bytes in both orientations from dvlp_dropout_attn_mask and
                                 1 / (1 - p) -- HF MultiHeadSelfAttention's `weights = dropout(softmax(scores))`
@@ -212,30 +174,12 @@ int dvlp_dropout_attn_mask(int64_t BH, int64_t N, float p, const void* state, in
 int dvlp_philox_kat(const void* ctr_key, void* out, void* stream);
 
 /* ---- local loss: xattn_score_fast / func_attention_fast / focal_equal / cosine_similarity (model/loss.py:209-330) ---- */
-/* testing knob: 1 = always take the general-G (long-video) softmax path, even when the fused per-pair kernels fit LDS */
-int dvlp_dev_xattn_force_general(int on);
-/* 1 (default): bf16 pairs with F*R <= 288, W <= 112 run the fused per-pair kernels (everything between the embeddings and the
-   score on chip); 0: always the multi-kernel path -- for A/B measurements and tests */
-int dvlp_dev_xattn_fused_mode(int mode);
-/* bf16 backward of the per-pair softmax stage: 1 (default) keeps both intermediate tiles on chip (LDS low halves / registers),
-   0 runs the generic kernel that round-trips them through the workspace -- for A/B measurements and tests */
-int dvlp_dev_xattn_bwd_variant(int packed);
-/* 1 (default): bf16 pairs that fit the per-pair LDS tile use the Gram form of the text->image direction -- cos(wc2_g, C_g) from
-   u_g = sum_w P2 S_raw and v_g = P2_g (Q^ Q^^T) P2_g^T, so the [Bj][Bi][G][d] weighted contexts are never formed (forward or backward);
-   0: the weighted contexts are materialised as in the reference -- for A/B measurements and tests */
-int dvlp_dev_xattn_gram(int on);
-/* 1 (default): bf16 backward with the per-pair LDS tile: the dP1 rows are produced with regions g and g + 64 of every full block of 128
-   adjacent (the product is handed a row-permuted copy of the unit regions), so the backward fetches them as 4-byte pieces; 0: natural
-   order -- for A/B measurements and tests */
-int dvlp_dev_xattn_pair_regions(int on);
-/* 1: the text->image half of the local loss (its contractions and cosine passes) is issued on an internal side stream beside the
-   image->text half between the softmax stages (fork / join by events, capturable; default since round 5); 0: everything on the caller's stream */
-int dvlp_dev_xattn_parallel_halves(int on);
-/* TIMING-ONLY ablation of the bf16 per-pair backward kernel: leave after stage 6 (launch + dP1 rows requested), 5 (S tile staged), 1 (+ norms),
-   2 (image->text pass), 3 (text->image pass); 0 in production (tools/xbwd_stages.py) */
-int dvlp_dev_xattn_bwd_stop(int stage);
-/* TIMING-ONLY ablation of the fused forward kernel (stop after phase n); 0 in production */
-int dvlp_dev_xfused_ablate(int stop);
+/* `gate`: bit 0 = focal_equal gate on (model/loss.py:274-283); bit 1 (DVLP_XATTN_ONE_STREAM) = issue everything on the caller's stream --
+   by default the text->image half of the multi-kernel path (its contractions and cosine passes) runs on an internal side stream beside
+   the image->text half between the softmax stages (fork / join by events, capturable into a hipGraph; its split-K slabs are a region of
+   `workspace` of their own).  A per-call option, not process state: bench.py's per-launch timing pass sets it so that an event pair
+   brackets one launch. */
+enum { DVLP_XATTN_GATE = 1, DVLP_XATTN_ONE_STREAM = 2 };
 int64_t dvlp_xattn_workspace_bytes(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int bwd);
 int dvlp_xattn_fwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int64_t d, const void* Craw, const void* Qraw,
                    const float* mimg, const float* mcap, float lam, int gate, float* scores, void* workspace, int bwd, void* stream);
@@ -248,9 +192,6 @@ int dvlp_xattn_bwd(int dtype, int64_t Bi, int64_t Bj, int64_t G, int64_t W, int6
 int dvlp_global_local_loss(int dtype, int64_t B, int64_t d, const void* gt, const void* go, const float* xs, float temperature,
                            float lam, int use_global, int use_local, int stages, float* sim, float* dsim, void* dgt, void* dgo,
                            float* dxs, float* losses, void* stream);
-/* 1 (default): bf16 embeddings with B = 32 / 64 run the three B x B x 256 products of the launch on the matrix cores; 0: the
- * one-wave-per-entry form used for every other shape -- for A/B measurements and tests */
-int dvlp_dev_loss_mfma(int on);
 
 /* rectangular sim_matrix (model/model.py:582-590 on [N,256] x [M,256], e.g. the whole eval set at trainer/trainer_dist.py:369):
    xn (fp32) = x / max(|x|, 1e-8) row-wise and norm = |x|; the [N,M] product and its two gradient products are dvlp_gemm calls in

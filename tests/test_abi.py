@@ -17,8 +17,8 @@ def lib():
     return _lib
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "demovlp_hip.h")).read()
+def declared_symbols(header="demovlp_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dvlp_\w+)\s*\(", text)))
 
@@ -30,6 +30,33 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/demovlp_hip.h but not exported"
     assert set(lib.exported_symbols()) == set(names)
+
+
+def test_product_library_exports_no_developer_switch(lib):
+    """`dvlp_dev_*` (A/B switches, timing ablations, forced code paths) exist only in the -DDVLP_DEV build: the shipped library has no
+    process-global knob to flip (`nm -D libdemovlp_hip.so | grep dvlp_dev_` is empty), the developer build exports all of them on top of the
+    product surface, and asking the product library for one fails loudly."""
+    import subprocess
+    assert not any(n.startswith("dvlp_dev_") for n in declared_symbols())
+    dev = declared_symbols("demovlp_hip_dev.h")
+    assert len(dev) >= 20 and all(n.startswith("dvlp_dev_") for n in dev)
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "dvlp_dev_" not in syms and "dvlp_gemm" in syms
+    handle = ctypes.CDLL(lib.DEV_LIB_PATH)
+    for n in dev + declared_symbols():
+        assert hasattr(handle, n), f"{n} missing from the developer build"
+    lib.use_dev_library(False)            # (conftest put this test on the developer build because it names the switch)
+    assert lib.active_library() == lib.LIB_PATH and not lib.is_dev_library()
+    with pytest.raises(lib.DemoVLPHipError):
+        lib.call("dvlp_dev_gemm_p8_mode", 2)
+    lib.use_dev_library(True)
+    try:
+        assert lib.is_dev_library()
+        lib.call("dvlp_dev_gemm_p8_mode", 1)
+        assert lib.call("dvlp_colsum_chunks", 100) == 2
+    finally:
+        lib.use_dev_library(False)
+    assert not lib.is_dev_library()
 
 
 def test_size_helpers_run_on_host(lib):

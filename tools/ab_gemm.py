@@ -11,6 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from demovlp_amd import _lib  # noqa: E402
+from demovlp_amd import _lib as _dvlp_lib  # noqa: E402
+_dvlp_lib.use_dev_library()     # developer switches (dvlp_dev_*) exist only in libdemovlp_hip_dev.so
 
 libs = {"new": _lib.load()}
 prev = ctypes.CDLL(os.path.abspath(sys.argv[1]))

@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from demovlp_amd import ops  # noqa: E402
+from demovlp_amd import _lib as _dvlp_lib  # noqa: E402
+_dvlp_lib.use_dev_library()     # developer switches (dvlp_dev_*) exist only in libdemovlp_hip_dev.so
 
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)

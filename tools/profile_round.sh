@@ -12,7 +12,7 @@ python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc
 # the PMC passes FIRST, their summary written into profiles/ on this box, THEN the bench line: its roofline.traffic then names counters that were
 # taken on exactly these kernels in this very run (round 3's set had a bench line from before its PMC passes: traffic null).
 # usage: tools/profile_round.sh <tag> [git head]   (the GPU box has no .git: the caller passes the revision)
-TAG=${1:-r5_final}
+TAG=${1:-r6_final}
 export DVLP_GIT_HEAD=${2:-}
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline > /dev/null 2> $O/write.err

@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from demovlp_amd import _lib  # noqa: E402
+from demovlp_amd import _lib as _dvlp_lib  # noqa: E402
+_dvlp_lib.use_dev_library()     # developer switches (dvlp_dev_*) exist only in libdemovlp_hip_dev.so
 
 lib = _lib.load()
 dev = "cuda"

@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from demovlp_amd import ops  # noqa: E402
+from demovlp_amd import _lib as _dvlp_lib  # noqa: E402
+_dvlp_lib.use_dev_library()     # developer switches (dvlp_dev_*) exist only in libdemovlp_hip_dev.so
 
 B, G, W = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 288, 99)
 ONLY = int(os.environ["XLOSS_ONLY"]) if "XLOSS_ONLY" in os.environ else None      # profile one variant
