@@ -312,12 +312,12 @@ def main():
     gather = None
     if a.gather_negatives and (world > 1 or force_dist):
         gather = argparse.Namespace(world_size=world, rank=rank)
-    use_graph = bool(a.graph) and gather is None
+    use_graph = bool(a.graph)
     model.parallel_towers = bool(a.parallel_towers)
     reducer, stepper = None, None
     if use_graph:
         stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, always_reduce=force_dist, grad_dtype="bfloat16" if a.grad_dtype == "bf16" else "float32",
-                                   exchange=a.exchange)
+                                   exchange=a.exchange, gather_negatives=gather)
     elif world > 1 or force_dist:
         reducer = GradReducer(arena, bucket_mb=64.0, always_reduce=force_dist)
 

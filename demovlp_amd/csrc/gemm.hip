@@ -1159,7 +1159,7 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
     auto row_of = [&](int ii) { return m0 + (ii < 4 ? 64 * wr : 128 + 16 * MIH * wr) + 16 * (ii & 3) + r16; };
     if (!PERS && slab_out && n0 + 256 <= N && (N & 3) == 0) {
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
+        for (int ii = 0; ii < 4 + MIH; ++ii) {
             const int64_t m = row_of(ii);
             if (m < M) {
                 float* dst = slab_out + m * N + n0 + 32 * wc + 4 * g4;
@@ -1234,7 +1234,11 @@ __device__ __forceinline__ void p8_tile(char* smem_raw, int64_t M, int64_t N, co
         }
         return;
     }
-    if constexpr (MIH != 4 || PERS) return;      // short tiles / the persistent form are only dispatched when every tile takes the path above
+    // Only the run-time-flag kernel (EK = anything) carries the ragged path: the specialised kinds, the short tiles and the persistent form
+    // are dispatched when every tile takes one of the two paths above (N a multiple of 256; aligned outputs unless split).  Round 6: with the
+    // ragged path (an out-of-line call that keeps two copies of the epilogue descriptor alive) in every 256-row instantiation, each carried
+    // 30-38 spilled SGPRs; the text tower's split-K launches ran on them.
+    if constexpr (EK != P8_EK_ANY || MIH != 4 || PERS) return;
     // ragged tiles / unaligned outputs: four 32-row passes through LDS (rows {lo, hi} x {first, second 32}; a pass covers the
     // wave's 32 + 32 columns), scalar epilogue out of line
     constexpr int P_EPW = 32 * 68 * 4;                         // bytes per wave: staged accumulators
@@ -1536,6 +1540,31 @@ struct dvlp_gemm_ext {
     int colsum_fused;       // out: 1 = queued from inside the GEMM's epilogue (final after the deferred reductions are flushed), 0 = a plain pass ran
 };
 
+// Tile height x K split of the 256-column kernel for an under-filled or round-quantised output (round 6).  What a block costs is not
+// proportional to its rows: per 64-deep K tile ~ (0.55 + 0.0016 rows) us on a lightly filled chip, up to ~1.35x that when every CU streams
+// (clock and L2 share), plus a prologue + epilogue of ~ (6 + 0.028 rows) us; a K split adds the slab round trip and the reduction launch
+// (~2.5 us + 1.08 us per million output elements and slice).  Constants fitted to tools/tile_sweep.py on MI355X (profiles/r6_tile_sweep.txt:
+// M = 6400 / 7712 / 18496 tokens x the eight forward / dX shapes of a layer); the model only has to RANK the candidates.
+struct P8Plan { int mih; int64_t S; };
+static P8Plan p8_plan(int64_t M, int64_t N, int64_t K, int64_t ntn8, int ncu, bool may_split, int64_t ws_bytes) {
+    const int64_t nk = K / 64;
+    P8Plan best{4, 1};
+    double best_c = 1e30;
+    for (int h = 4; h >= 1; --h) {
+        const int64_t rows = 128 + 32 * h, nb1 = cdiv(M, rows) * ntn8;
+        for (int64_t S = 1; S <= (may_split ? 4 : 1); ++S) {
+            if (S > 1 && (nk < 8 * S || nb1 >= 200 || S * M * N * 4 > ws_bytes)) break;
+            const int64_t nb = nb1 * S, rounds = cdiv(nb, ncu);
+            const double fill = (double)nb / (double)(rounds * ncu);
+            const double crowd = 1.0 + 0.35 * (fill > 0.3 ? (fill - 0.3) / 0.7 : 0.0);
+            const double tk = (0.55 + 0.0016 * rows) * crowd, fixed = 6.0 + 0.028 * rows;
+            const double c = rounds * ((double)cdiv(nk, S) * tk + fixed) + (S > 1 ? 2.5 + 1.08e-6 * (double)S * (double)M * (double)N : 0.0);
+            if (c < best_c * 0.995) { best_c = c; best = P8Plan{h, S}; }        // (ties go to the taller tile / the smaller split: tried first)
+        }
+    }
+    return best;
+}
+
 static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                              const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, const void* res, int64_t ldres,
                              void* aux, int64_t ldaux, int flags, float alpha, int64_t batch, int64_t strideA, int64_t strideB,
@@ -1606,13 +1635,29 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         const WsEntry wse = ws_for(stream);
         float* g_ws = wse.ptr;
         const int64_t g_ws_bytes = wse.bytes;
-        if (g_ws && tiles < (p8 ? 128 : 200) && K >= 1024) {
-            S = p8 ? 256 / tiles : (g_splitk_target + tiles - 1) / tiles;
-            if (S > K / 256) S = K / 256;
-            if (S > 32) S = 32;
-            while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;
+        static const int ncu8 = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+        // tile height (p8_tile_rows) and K split of the 256-column kernel, chosen TOGETHER where every tile takes a whole-tile store (row-major
+        // A, whole 256-column tiles, aligned outputs; a split launch writes slabs, which any height can): p8_plan above.  M = 18496: 224-row
+        // tiles (83 x {3, 9, 12} = 249 / 747 / 996 blocks fill 1 / 3 / 4 rounds of 256 CUs that 256-row tiles leave 14 % empty); M = 6400
+        // (the text tower): 160-row tiles (120 / 480 blocks instead of 75 / 300), K >= 2304 as 160 rows x 2 slices instead of 256 x 3.
+        int mih8 = 4;
+        const bool plan8 = p8 && g_p8_short != 0 && !transA && batch == 1 && N % 256 == 0 && e.vec && (N & 3) == 0;
+        if (plan8 && g_p8_short == 1 && g_force_split == 0) {
+            const P8Plan pl = p8_plan(M, N, K, ntn8, ncu8, g_ws != nullptr && K >= 1024, g_ws_bytes);
+            mih8 = pl.mih; S = pl.S;
+        } else {
+            if (g_ws && tiles < (p8 ? 128 : 200) && K >= 1024) {
+                S = p8 ? 256 / tiles : (g_splitk_target + tiles - 1) / tiles;
+                if (S > K / 256) S = K / 256;
+                if (S > 32) S = 32;
+                while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;
+            }
+            if (g_force_split > 0 && g_ws) { S = g_force_split; while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S; }
+            if (plan8) {           // developer switches: a forced height (10 + MIH) or "224 wherever allowed" (2)
+                if (g_p8_short >= 10) mih8 = g_p8_short - 10 >= 1 && g_p8_short - 10 <= 4 ? g_p8_short - 10 : 4;
+                else if (g_p8_short == 2) mih8 = 3;
+            }
         }
-        if (g_force_split > 0 && g_ws) { S = g_force_split; while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S; }
         int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;
         S = cdiv(K, kchunk);
         float* slab = S > 1 ? g_ws : nullptr;
@@ -1631,9 +1676,10 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         hipLaunchKernelGGL((gemm_bf16_p8p_kernel<AR, BR, EK, MIH>), dim3((unsigned)ncu8), dim3(512), (size_t)P_LDS_TOTAL, st, M, N, K, (const bf16*)A, lda, \
                            (const bf16*)B, ldb, (bf16*)C, ldc, e, (int)ntm8h, (int)ntn8); } while (0)
 #define LAUNCH_P8S_(AR, BR, EK) do { if constexpr (!AR && (EK == 0 || EK == 2)) { if (p8p) { LAUNCH_P8P_(AR, BR, EK, 3); break; } } if constexpr (!AR) { \
-        if (mih8 == 3) { LAUNCH_P8K_(AR, BR, EK, 3); break; } } LAUNCH_P8K_(AR, BR, EK, 4); } while (0)
+        if (mih8 == 3) { LAUNCH_P8K_(AR, BR, EK, 3); break; } if (mih8 == 2) { LAUNCH_P8K_(AR, BR, EK, 2); break; } if (mih8 == 1) { LAUNCH_P8K_(AR, BR, EK, 1); break; } } \
+        LAUNCH_P8K_(AR, BR, EK, 4); } while (0)
 #define LAUNCH_P8_(AR, BR) do { if (ek8 == 0) LAUNCH_P8S_(AR, BR, 0); else if (ek8 == 1) LAUNCH_P8S_(AR, BR, 1); else if (ek8 == 2) LAUNCH_P8S_(AR, BR, 2); \
-        else if (ek8 == 3) LAUNCH_P8S_(AR, BR, 3); else LAUNCH_P8K_(AR, BR, P8_EK_ANY, 4); } while (0)
+        else if (ek8 == 3) LAUNCH_P8S_(AR, BR, 3); else if (mih8 != 4) LAUNCH_P8S_(AR, BR, 0); else LAUNCH_P8K_(AR, BR, P8_EK_ANY, 4); } while (0)
 #define LAUNCH_GLDS_(AR, BR) do { if (p8) LAUNCH_P8_(AR, BR); else if (wide) { static bool once = false; if (!once) { once = true; \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<AR, BR, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128); } \
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<AR, BR, 4, 3>), gridw, dim3(512), (size_t)3 * (256 + 128) * 128, st, M, N, K, (const bf16*)A, lda, \
@@ -1647,17 +1693,12 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         dim3 gridw((unsigned)(ntm_w * ntn), (unsigned)batch, (unsigned)S);
         // epilogue kind of the 256-row kernel (see p8_tile)
         const int fmask8 = flags & (EPI_GELU | EPI_GELU_BWD | EPI_RELU_BWD | EPI_ACCUM | EPI_OUT_F32);
-        const int ek8 = g_ablate ? P8_EK_ANY : fmask8 == 0 ? (res ? 1 : 0) : (fmask8 == EPI_GELU && !res) ? 2 : (fmask8 == EPI_GELU_BWD && !res) ? 3 : P8_EK_ANY;
-        // tile height (p8_tile_rows): 224-row tiles when they need fewer CU-rounds x rows than 256-row ones (M = 18496: 83 x {3, 9, 12}
-        // = 249 / 747 / 996 tiles fill 1 / 3 / 4 rounds of 256 CUs that 219 / 657 / 876 tiles of 256 rows leave 14 % empty).  Only where
-        // every tile takes the whole-tile epilogue: row-major A, whole 256-column tiles, aligned outputs, no K split.
-        static const int ncu8 = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
-        int mih8 = 4;
-        if (p8 && g_p8_short != 0 && !transA && S == 1 && batch == 1 && N % 256 == 0 && e.vec && ek8 != P8_EK_ANY) {
-            const int64_t t224 = cdiv(M, 224) * ntn8;
-            if (g_p8_short == 2 || cdiv(t224, ncu8) * 224 < cdiv(tiles8, ncu8) * 256) mih8 = 3;
-        }
-        const int64_t ntm8h = mih8 == 3 ? cdiv(M, 224) : ntm8;
+        // (a specialised kind only where every tile is whole: N a multiple of 256 and, unless the launch writes split-K slabs, 16-byte aligned outputs)
+        const bool whole8 = N % 256 == 0 && (S > 1 ? N % 4 == 0 : e.vec != 0);
+        const int ek8 = (g_ablate || !whole8) ? P8_EK_ANY : (S > 1 || fmask8 == 0) ? ((res && S == 1) ? 1 : 0) : (fmask8 == EPI_GELU && !res) ? 2 : (fmask8 == EPI_GELU_BWD && !res) ? 3 : P8_EK_ANY;
+        if (ek8 == P8_EK_ANY && S == 1) mih8 = 4;        // run-time-flag epilogues exist at 256 rows only
+        const int64_t rows8 = 128 + 32 * mih8;
+        const int64_t ntm8h = cdiv(M, rows8);
         if (csum_dst && p8 && batch == 1 && S == 1 && e.vec && N % 256 == 0 && !(flags & EPI_OUT_F32)) {
             e.csum = dvlp_rd_reserve_push(2 * ntm8h, N, csum_dst);     // partial rows: (row tile, upper / lower wave group)
             csum_fused = e.csum != nullptr;

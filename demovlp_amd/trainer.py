@@ -426,10 +426,27 @@ def gather_embeddings(out, text_length, text_mask, args):
     return gathered, _gather_plain(text_length, n_gpu), _gather_plain(text_mask, n_gpu)
 
 
-def backward_first(model, loss_fn, data, gather_negatives=None):
-    """trainer/trainer_dist.py:148-165: forward, masks, sim_matrix, GlobalLocalLoss and ``loss.backward()``.  When the object tower
-    carries a ``grad_cut`` the backward stops at that block's input (text tower, heads and the upper object blocks are done; their
-    gradients are final when this returns) and ``backward_second`` finishes it.  Returns the three detached losses."""
+class _AdoptGathered(torch.autograd.Function):
+    """``AllGather_multi`` with the collective ALREADY done: forward hands out the buffer every rank's slice was gathered into, backward
+    returns the local slice of its gradient (trainer/trainer_dist.py:25-31).  Launches nothing -- what lets ``GraphedTrainStep`` keep the
+    all-gather outside its hipGraphs: the forward graph ends at the local embeddings, the collective runs between two replays, and the
+    loss graph starts from the gathered buffers."""
+
+    @staticmethod
+    def forward(ctx, local, gathered, rank):
+        ctx.rank, ctx.batch_size = rank, local.shape[0]
+        return gathered.view(gathered.shape)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output[ctx.batch_size * ctx.rank:ctx.batch_size * (ctx.rank + 1)], None, None
+
+
+GATHERED_KEYS = ("global_text_embeddings", "local_text_embeddings", "global_object_embeddings", "local_object_embeddings", "object_mask")
+
+
+def forward_only(model, data):
+    """trainer/trainer_dist.py:148-159: the model's forward and the caption-side inputs of the loss.  -> (out dict, text_length, text_mask)"""
     att = data["text"]["attention_mask"]
     out = model(data)
     if att.is_cuda and att.dtype == torch.int64 and att.dim() == 2 and att.shape[1] >= 2:
@@ -437,8 +454,11 @@ def backward_first(model, loss_fn, data, gather_negatives=None):
     else:
         text_length = torch.sum(att, dim=1)
         text_mask = (att[:, 1:] - 1.0) * 100.0                   # (:156-159; the subtraction already yields a contiguous tensor)
-    if gather_negatives is not None:
-        out, text_length, text_mask = gather_embeddings(out, text_length, text_mask, gather_negatives)
+    return out, text_length, text_mask
+
+
+def loss_backward_first(model, loss_fn, out, text_length, text_mask):
+    """trainer/trainer_dist.py:160-165: sim_matrix, GlobalLocalLoss and ``loss.backward()`` (down to the object tower's topmost open cut)."""
     global_sim = sim_matrix(out["global_text_embeddings"], out["global_object_embeddings"])
     loss, global_loss, local_loss = loss_fn(global_sim, out["local_object_embeddings"], out["local_text_embeddings"],
                                             out["object_mask"], text_length, text_mask)
@@ -446,6 +466,16 @@ def backward_first(model, loss_fn, data, gather_negatives=None):
     if loss.is_cuda:
         Fn.join_side_stream()          # weight gradients (side stream) and the text tower's stream
     return loss.detach(), global_loss.detach(), local_loss.detach()
+
+
+def backward_first(model, loss_fn, data, gather_negatives=None):
+    """trainer/trainer_dist.py:148-165: forward, masks, sim_matrix, GlobalLocalLoss and ``loss.backward()``.  When the object tower
+    carries a ``grad_cut`` the backward stops at that block's input (text tower, heads and the upper object blocks are done; their
+    gradients are final when this returns) and ``backward_second`` finishes it.  Returns the three detached losses."""
+    out, text_length, text_mask = forward_only(model, data)
+    if gather_negatives is not None:
+        out, text_length, text_mask = gather_embeddings(out, text_length, text_mask, gather_negatives)
+    return loss_backward_first(model, loss_fn, out, text_length, text_mask)
 
 
 def backward_next(model):
@@ -524,7 +554,7 @@ class GraphedTrainStep:
     shape -- a loader's smaller last batch -- runs ``warmup`` eager steps of its own, is captured, and from then on both shapes replay."""
 
     def __init__(self, model, loss_fn, optimizer: FusedAdamW, warmup: int = 2, group=None, bucket_mb: float = 64.0, always_reduce: bool = False,
-                 cut=(8, 4), grad_dtype: str = "float32", time_exchange: bool = False, exchange: str = "all_reduce"):
+                 cut=(8, 4), grad_dtype: str = "float32", time_exchange: bool = False, exchange: str = "all_reduce", gather_negatives=None):
         """``grad_dtype='bfloat16'``: every bucket crosses the links as bf16 (half the bytes: 292 instead of 584 MB per step) -- cast by a
         kernel into a staging buffer, summed by the collective in bf16, cast back into the fp32 gradient arena, where the optimizer reads
         it; moments and master weights stay fp32.  Two extra HBM passes per bucket (12 B per parameter beside the update's 30).
@@ -534,12 +564,17 @@ class GraphedTrainStep:
         ``all_gather_into_tensor``: the two DIRECT collectives that put all seven xGMI links of a GPU to work at once instead of one ring
         hop at a time (0.18 against 1.3 ms for the exposed last piece at 8 GPUs, on paper).  With ``grad_dtype='bfloat16'``
         the scatter stays fp32 and only the gather crosses as bf16 (one rounding, whatever the world size; 6 instead of 4 bytes per element
-        on the links).  NCCL / RCCL groups only; other backends (gloo in the CPU tests) take the all-reduce path.  Unmeasured on > 1 GPU."""
+        on the links).  NCCL / RCCL groups only; other backends (gloo in the CPU tests) take the all-reduce path.  Unmeasured on > 1 GPU.
+        ``gather_negatives``: None (the reference's training: per-rank negatives) or an object with ``world_size`` / ``rank`` (the reference's
+        ``args``): the contrastive losses run over the all-gathered embeddings of every rank with ``AllGather_multi``'s backward (the local
+        slice, trainer/trainer_dist.py:13-31).  The step is then captured as a FORWARD graph (both towers, up to the local embeddings) and the
+        loss / backward graphs; the all-gather runs between them, outside any capture, into persistent buffers the loss graph reads."""
         if grad_dtype not in ("float32", "bfloat16"):
             raise ValueError("grad_dtype must be 'float32' or 'bfloat16'")
         if exchange not in ("all_reduce", "rs_ag"):
             raise ValueError("exchange must be 'all_reduce' or 'rs_ag'")
         self.exchange = exchange
+        self.gather, self._gbuf, self._gbufs, self._fwd = gather_negatives, None, {}, None
         self.exchange_used, self._warned = set(), False       # the forms actually taken (bench.py reports them), one warning on an emulated one
         self.grad_dtype, self.time_exchange, self._xev, self._stage = grad_dtype, bool(time_exchange), [], None
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
@@ -640,19 +675,38 @@ class GraphedTrainStep:
 
     # ---- the step as a list of pieces: piece 0 = forward + losses + the top of the backward, piece k = the next stretch of it --------
     def _piece(self, k, data):
-        last = k == len(self.cuts)
+        """Piece k of the step.  With ``gather_negatives`` the pieces are shifted by one: piece -1... is numbered 0 = the forward alone
+        (``n_pieces`` = cuts + 2), the all-gather follows it outside the graphs (``_gather``), piece 1 = losses + the top of the backward."""
+        g = 1 if self.gather is not None else 0
+        last = k == len(self.cuts) + g
         if k == 0:
             self.opt.zero_grad()
             if not self.collective:
                 self.opt.begin_overlapped()
             self._set_cut()
             try:
-                self.out = backward_first(self.model, self.loss_fn, data)
+                if g:
+                    self._fwd = forward_only(self.model, data)
+                else:
+                    self.out = backward_first(self.model, self.loss_fn, data)
             except BaseException:
                 self.opt.abort_overlapped()
                 raise
             finally:
                 self._set_cut(False)
+            if not g:
+                self.opt._adopt_stray_grads()
+            else:
+                return
+        elif g and k == 1:
+            out, tl, tm = self._fwd
+            rank = self.gather.rank
+            gathered = {key: (_AdoptGathered.apply(out[key], self._gbuf[key], rank) if out[key].requires_grad else self._gbuf[key]) for key in GATHERED_KEYS}
+            try:
+                self.out = loss_backward_first(self.model, self.loss_fn, gathered, self._gbuf["text_length"], self._gbuf["text_mask"])
+            except BaseException:
+                self.opt.abort_overlapped()
+                raise
             self.opt._adopt_stray_grads()
         else:
             backward_next(self.model)
@@ -666,6 +720,35 @@ class GraphedTrainStep:
             self.opt.prepare()
             if not self.collective:
                 self.opt.launch(grad_scale=1.0)
+
+    def _gather_buffers(self):
+        """The persistent gathered buffers for the shapes of the last forward (one set per shape, kept for as long as this object lives: a
+        captured loss graph points at them).  Allocates outside captures only."""
+        out, tl, tm = self._fwd
+        world = self.gather.world_size
+        local = dict(out)
+        local["text_length"], local["text_mask"] = tl, tm
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in local.items())
+        buf = self._gbufs.get(key)
+        if buf is None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("gather buffers would be allocated inside a hipGraph capture")
+            buf = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), device=v.device, dtype=v.dtype) for k, v in local.items()}
+            self._gbufs[key] = buf
+        self._gbuf = buf
+        return local, buf
+
+    def _gather(self):
+        """Between the forward graph and the loss graph, outside any capture: every rank's embeddings, masks and caption lengths into the
+        persistent buffers the loss piece adopts (rank order along dim 0, as ``torch.cat(all_gather(...))`` -- trainer_dist.py:17-23)."""
+        local, buf = self._gather_buffers()
+        world = self.gather.world_size
+        if dist.is_initialized() and world > 1:
+            for k, v in local.items():
+                dist.all_gather(list(buf[k].chunk(world, 0)), v.detach().contiguous(), group=self.group)
+        else:
+            for k, v in local.items():
+                buf[k].copy_(v.detach())
 
     def _exchange_and_update(self, runs, piece=0):
         """All-reduce the given arena ranges of the gradient buffer (sum) and update the parameters of each reduced piece: collectives
@@ -835,7 +918,8 @@ class GraphedTrainStep:
             Fn.SHADOWS.invalidate()
 
     def _run_pieces(self, data, graphs=None):
-        n = len(self.cuts) + 1
+        g = 1 if self.gather is not None else 0
+        n = len(self.cuts) + 1 + g
         if self.collective and self.opt.arena.flat_g.is_cuda:
             self._begin_updates()
         try:
@@ -844,8 +928,11 @@ class GraphedTrainStep:
                     graphs[k].replay()
                 else:
                     self._piece(k, data)
+                if g and k == 0:
+                    self._gather()                       # the embedding all-gather: outside the graphs, between the forward and the loss
+                    continue
                 if self.collective:
-                    self._exchange_and_update(self.piece_runs[k], piece=k)
+                    self._exchange_and_update(self.piece_runs[k - g], piece=k - g)
         except BaseException:
             # _begin_updates() advanced the device step counter and earlier pieces may already be updated (their moments too): the
             # host count did not move, so have the next _sync_hyper() rewrite the device counter from it
@@ -897,13 +984,15 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.opt._sync_hyper(1.0 / self.world)              # no host->device copy may happen inside the capture
         self.graphs = []
-        for k in range(len(self.cuts) + 1):                 # graphs sharing one memory pool: each consumes what the previous ones saved
+        for k in range(len(self.cuts) + 1 + (1 if self.gather is not None else 0)):     # graphs sharing one memory pool: each consumes what the previous ones saved
             g = torch.cuda.CUDAGraph()
             # ops.graph_capture: thread_local error mode (a loader thread keeps working while this thread captures) and the eager stream's
             # cached scratch (nothing that is cached may live in this graph's private pool)
             with ops.graph_capture(g, pool=self.graphs[0].pool() if self.graphs else None):
                 self._piece(k, self.static)
             self.graphs.append(g)
+            if self.gather is not None and k == 0:
+                self._gather_buffers()                        # (shapes only: the collective itself runs between REPLAYS, never here)
         if not self.collective:
             self.opt.step_count -= 1                          # launch() counted a step, but capturing executed nothing
 
@@ -921,10 +1010,10 @@ class GraphedTrainStep:
             if len(self._sets) >= self.max_shapes:
                 self._sets.pop(next(iter(self._sets)))        # least recently used capture (its memory pool goes with it)
             self._capture(data)
-            self._sets[key] = (self.graphs, self.static, self.out)
+            self._sets[key] = (self.graphs, self.static, self.out, self._fwd, self._gbuf)
         else:
             self._sets[key] = self._sets.pop(key)             # most recently used last: eviction takes the front
-            self.graphs, self.static, self.out = have
+            self.graphs, self.static, self.out, self._fwd, self._gbuf = have
             self.shape_key = key
             for k, v in data["text"].items():
                 self._put(self.static["text"][k], v)

@@ -569,6 +569,81 @@ def golden_pretrained_init(ref_model):
     np.savez_compressed(os.path.join(HERE, "g13_pretrained_init.npz"), **out)
 
 
+def golden_finetune_then_eval(ref_model, ref_loss):
+    """G14: BASELINE config 4 end to end -- configs/ft/msrvtt_o2t-select.json geometry (F = 8, R = 30, per-GPU batch 32): the imported
+    reference FINE-TUNES for 10 optimisation steps (trainer/trainer_dist.py:104-203: zero_grad, forward, sim_matrix, GlobalLocalLoss,
+    backward, HF-AdamW step; train mode, dropout 0) from the retrieval weights of G11 on ten training batches (pairs 256 .. 575 of the
+    synthetic retrieval set), then VALIDATES (`_valid_epoch`, :205-408, driven by hand with n_gpu = 1 as in G9 / G11) on the 256-pair G11
+    set.  At the config's lr (1e-5) and at the lr the reference's `_adjust_learning_rate` quirk uses from the second epoch on (2e-4).
+    Stored: the two 10-step loss curves, and after each fine-tune the validation losses, o2t similarity matrix and t2v / v2t metrics."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("refmetric", "/root/reference/model/metric.py")
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    F, R, BS, NB, STEPS, FIRST_TRAIN = 8, 30, 32, 8, 10, 256
+    sd = syn.retrieval_state_dict(F, R)
+    keys = ("R1", "R5", "R10", "R50", "MedR", "MeanR", "geometric_mean_R1-R5-R10")
+    out = dict(F=F, R=R, batch=BS, batches=NB, steps=STEPS, first_train_pair=FIRST_TRAIN)
+
+    def batch_of(first):
+        obj, mask, ids, att = syn.retrieval_batch(sd, F, R, first, BS)
+        return {"text": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(att)}, "object": torch.from_numpy(obj),
+                "object_mask": torch.from_numpy(mask)}
+
+    for tag, lr in (("lr1e-5", 1e-5), ("lr2e-4", 2e-4)):
+        m = build_reference_model(ref_model, F, R)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(torch.from_numpy(sd[k]))
+        m.train()
+        opt = HFAdamW(filter(lambda p: p.requires_grad, m.parameters()), lr=lr)
+        loss_fn = ref_loss.GlobalLocalLoss(use_local=True, use_global=True, coef=1.0, focal_type="equal")
+        curve = []
+        for step in range(STEPS):
+            t0 = time.time()
+            data = batch_of(FIRST_TRAIN + step * BS)
+            opt.zero_grad()
+            o = m(data)
+            text_mask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+            text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+            gsim = ref_model.sim_matrix(o["global_text_embeddings"], o["global_object_embeddings"])
+            loss, gl, ll = loss_fn(gsim, o["local_object_embeddings"], o["local_text_embeddings"], o["object_mask"], text_length, text_mask)
+            loss.backward()
+            opt.step()
+            curve.append([loss.item(), gl.item(), ll.item()])
+            print("g14", tag, "train", step, curve[-1], "%.1f s" % (time.time() - t0), flush=True)
+        out[tag + "_curve"] = np.array(curve, np.float64)
+        m.eval()
+        acc = {k: [] for k in ("gt", "go", "lt", "lo", "len", "om", "tm")}
+        val = []
+        with torch.no_grad():
+            for b in range(NB):
+                data = batch_of(b * BS)
+                text_length = torch.sum(data["text"]["attention_mask"], dim=1)
+                text_mask = (data["text"]["attention_mask"][:, 1:].contiguous() - 1.0) * 100.0
+                o = m(data, return_embeds=True)
+                for k, v in zip(acc, (o["global_text_embeddings"], o["global_object_embeddings"], o["local_text_embeddings"],
+                                      o["local_object_embeddings"], text_length, o["object_mask"], text_mask)):
+                    acc[k].append(v)
+                loss, gl, ll = loss_fn(ref_model.sim_matrix(o["global_text_embeddings"], o["global_object_embeddings"]), o["local_object_embeddings"],
+                                       o["local_text_embeddings"], o["object_mask"], text_length, text_mask)
+                val.append([loss.item(), gl.item(), ll.item()])
+            cat = {k: torch.cat(v) for k, v in acc.items()}
+            gs = ref_model.sim_matrix(cat["gt"], cat["go"]).detach().cpu().numpy()
+            ls = loss_fn.local_loss.get_sim_by_segment(cat["lo"], cat["lt"], cat["om"], cat["len"], cat["tm"], device="cpu")
+        o2t = gs + ls
+        out[tag + "_val_losses"] = np.array(val, np.float64)
+        out[tag + "_o2t_sims"] = o2t.astype(np.float32)
+        for name, fn in (("t2v", rm.t2v_metrics), ("v2t", rm.v2t_metrics)):
+            r = fn(o2t)
+            out[tag + "_" + name] = np.array([r[k] for k in keys], np.float64)
+            print("g14", tag, name, {k: round(float(r[k]), 3) for k in keys}, flush=True)
+        del m, opt
+    np.savez_compressed(os.path.join(HERE, "g14_finetune_eval.npz"), **out)
+    print("g14 written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -591,6 +666,8 @@ def main():
             golden_benchmark_curve(ref_model, ref_loss)
         if "g13" in only:
             golden_pretrained_init(ref_model)
+        if "g14" in only:
+            golden_finetune_then_eval(ref_model, ref_loss)
         return
     golden_region_select(ref_data, scratch)
     golden_xattn(ref_loss)
@@ -606,6 +683,7 @@ def main():
     golden_retrieval(ref_model, ref_loss)
     golden_benchmark_curve(ref_model, ref_loss)
     golden_pretrained_init(ref_model)
+    golden_finetune_then_eval(ref_model, ref_loss)
 
 
 if __name__ == "__main__":

@@ -212,6 +212,41 @@ def _gather_worker(rank, world, port, q, with_step):
         dist.destroy_process_group()
 
 
+def _graph_gather_worker(rank, world, port, q):
+    """GraphedTrainStep(gather_negatives=args): forward graph -> all-gather outside the graphs -> loss / backward graphs + bucketed gradient exchange."""
+    import argparse
+    import traceback
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        F, R, B = 8, 36, 2
+        model = build(F, R)
+        arena = ParamArena(model)
+        opt = FusedAdamW(arena, lr=1e-3)
+        args = argparse.Namespace(world_size=world, rank=rank)
+        data = to_dev(*_np_batch(F, R, B, rank, 0))
+        stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, gather_negatives=args)
+        losses, after2 = [], None
+        for s in range(5):                                   # 2 eager warm-ups, the capturing call, 2 replays
+            losses.append([float(t.item()) for t in stepper(data)])
+            if s == 1:
+                torch.cuda.synchronize()
+                after2 = arena.flat_p.double().cpu().numpy()[::211]
+        # a batch of ANOTHER shape (a loader's smaller last batch): its own warm-up, capture, buffers; then the first shape again
+        small = to_dev(*_np_batch(F, R, 1, rank, 3))
+        for s in range(4):
+            losses.append([float(t.item()) for t in stepper(small)])
+        losses.append([float(t.item()) for t in stepper(data)])
+        torch.cuda.synchronize()
+        info = dict(graphs=len(stepper.graphs or ()), sets=len(stepper._sets), steps=opt.step_count, gbufs=len(stepper._gbufs))
+        q.put((rank, losses, after2, arena.flat_p.double().cpu().numpy()[::211], info))
+    except BaseException:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_gather_negatives_two_ranks_on_device_vs_oracle():
     """AllGather_multi on device tensors at world 2: every rank computes GlobalLocalLoss over the 2B = 4 pairs of both ranks
     (forward within 1e-4 of the oracle's 4 x 4 loss, identical on both ranks), and its backward carries only the LOCAL slice of the
@@ -243,6 +278,23 @@ def test_gather_negatives_two_ranks_on_device_vs_oracle():
         assert np.isfinite(step_losses[1]) and step_losses[1] != step_losses[0]          # the update happened (lr 1e-3 overshoots on 4 pairs)
     assert np.abs(np.array(res[0][1]) - np.array(res[1][1])).max() < 1e-6 * abs(res[0][1][0])   # same 4 x 4 loss on both ranks
     assert np.array_equal(res[0][4], res[1][4])
+    # The same through GraphedTrainStep(gather_negatives=...) (round 6: bench.py --gather-negatives no longer drops to eager mode): the
+    # forward graph ends at the local embeddings, the all-gather runs between two replays, the loss / backward graphs start from the gathered
+    # buffers, the three-piece gradient exchange follows.  Its first two steps (eager warm-ups) and its replays must reproduce the eager
+    # train_step sequence above; ranks bit-equal; a batch of another shape gets buffers of its own.
+    gres = _spawn(_graph_gather_worker, ())
+    for rank in range(2):
+        _, gl, after2, pfin, info = gres[rank]
+        eager = res[rank][3]
+        assert abs(gl[0][0] - eager[0]) < 1e-5 * abs(eager[0]) and abs(gl[1][0] - eager[1]) < 1e-5 * abs(eager[1]), (gl[:2], eager)
+        assert np.abs(after2 - res[rank][4]).max() <= 1e-5 * max(1.0, np.abs(res[rank][4]).max())          # parameters after two steps = the eager path's
+        assert info["graphs"] == 4 and info["sets"] == 2 and info["gbufs"] == 2 and info["steps"] == 10, info
+        assert all(np.isfinite(x).all() for x in gl)
+    assert np.array_equal(gres[0][2], gres[1][2]) and np.array_equal(gres[0][3], gres[1][3])             # lock step through capture and replay
+    assert np.abs(np.array(gres[0][1]) - np.array(gres[1][1])).max() < 1e-6 * abs(gres[0][1][0][0])       # every rank sees the same 2B x 2B loss
+    # replays continue the eager sequence: the loss keeps moving and the 5th call (2nd replay) differs from the 3rd (the capturing call ran nothing,
+    # the replay behind it did)
+    assert gres[0][1][2] != gres[0][1][3] != gres[0][1][4]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
