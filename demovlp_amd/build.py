@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdemovlp_hip.so")
 DEV_LIB = os.path.join(LIBDIR, "libdemovlp_hip_dev.so")      # the same sources under -DDVLP_DEV: exports the dvlp_dev_* switches (tests, tools)
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "xattn.hip", "xfused.hip", "losses.hip", "select.hip", "optim.hip", "dropout.hip"]
+SOURCES = ["gemm.hip", "gemm_rb.hip", "norm.hip", "attention.hip", "embed.hip", "xattn.hip", "xfused.hip", "losses.hip", "select.hip", "optim.hip", "dropout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

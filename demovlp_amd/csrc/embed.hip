@@ -414,6 +414,19 @@ extern "C" int dvlp_text_mask_len(int64_t B, int64_t L, const int64_t* att, int6
     return dvlp_launch_status();
 }
 
+// DistilBERT's additive key mask from the attention mask, one launch (HF DistilBERT: scores.masked_fill(mask == 0, -inf)): key_mask[b][w] = 0 where
+// att[b][w] != 0, -inf elsewhere (fp32) -- the stock form is a zero fill, a comparison and a masked fill: three launches in every captured step.
+__global__ __launch_bounds__(256) void text_key_mask_kernel(int64_t n, const int64_t* __restrict__ att, float* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mask[i] = att[i] != 0 ? 0.f : -INFINITY;
+}
+extern "C" int dvlp_text_key_mask(int64_t B, int64_t L, const int64_t* att, float* key_mask, void* stream) {
+    dvlp_clear_status();
+    if (B <= 0 || L <= 0) return DVLP_ERR_SHAPE;
+    hipLaunchKernelGGL(text_key_mask_kernel, dim3((unsigned)cdiv(B * L, 256)), dim3(256), 0, (hipStream_t)stream, B * L, att, key_mask);
+    return dvlp_launch_status();
+}
+
 extern "C" int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
     dvlp_clear_status();
     if (n <= 0) return DVLP_ERR_SHAPE;

@@ -1451,6 +1451,10 @@ static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where
 DVLP_DEV_API int dvlp_dev_gemm_p8_mode(int mode) { g_p8_mode = mode; return DVLP_OK; }
 static int g_p8_persist = 1;     // persistent form of the 256-row kernel on multi-round outputs: 0 off, 1 on (default; A/B: tools/p8p_bench.py)
 DVLP_DEV_API int dvlp_dev_gemm_p8_persistent(int mode) { g_p8_persist = mode; return DVLP_OK; }
+static int g_rb = 1;             // resident-B streaming kernel (csrc/gemm_rb.hip) for batched skinny products: 0 never, 1 where its shapes fit (default)
+DVLP_DEV_API int dvlp_dev_gemm_resident_b(int on) { g_rb = on; return DVLP_OK; }
+bool dvlp_gemm_rb_try(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                      int64_t ldc, int64_t batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st);
 static int g_p8_short = 1;       // 224-row tiles of the 256-row kernel: 0 never, 1 where they save CU-rounds (default), 2 whenever allowed
 DVLP_DEV_API int dvlp_dev_gemm_p8_short_tiles(int mode) { g_p8_short = mode; return DVLP_OK; }
 static int g_force_split = 0;    // dvlp_gemm: 0 = automatic K split, > 0 = forced (A/B measurements: tools/gemm_sweep.py)
@@ -1603,6 +1607,9 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         else if (transA && transB) LAUNCH_F32(true, true);
         else LAUNCH_F32(true, false);
 #undef LAUNCH_F32
+    } else if (dtype == DVLP_BF16 && g_rb && !bias && !res && !aux && flags == 0 && alpha == 1.0f && !csum_dst && !g_ablate &&
+               dvlp_gemm_rb_try(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, batch, strideA, strideB, strideC, st)) {
+        rec.kern = 4;             // batched skinny product with its B operand resident in LDS (the local loss' per-video / per-caption contractions)
     } else if (dtype == DVLP_BF16) {
         // 16-byte vector loads need 8-element-aligned leading dims and base pointers
         if (lda % 8 || ldb % 8 || (uintptr_t)A % 16 || (uintptr_t)B % 16 || strideA % 8 || strideB % 8) return DVLP_ERR_SHAPE;
@@ -1653,9 +1660,10 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
                 while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S;
             }
             if (g_force_split > 0 && g_ws) { S = g_force_split; while (S > 1 && S * batch * M * N * 4 > g_ws_bytes) --S; }
-            if (plan8) {           // developer switches: a forced height (10 + MIH) or "224 wherever allowed" (2)
+            if (plan8) {           // developer switches: a forced height (10 + MIH), "224 wherever allowed" (2), round 5's rule (3)
                 if (g_p8_short >= 10) mih8 = g_p8_short - 10 >= 1 && g_p8_short - 10 <= 4 ? g_p8_short - 10 : 4;
                 else if (g_p8_short == 2) mih8 = 3;
+                else if (g_p8_short == 3 && S == 1 && cdiv(cdiv(M, 224) * ntn8, ncu8) * 224 < cdiv(tiles8, ncu8) * 256) mih8 = 3;
             }
         }
         int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;

@@ -542,6 +542,14 @@ def text_embed_bwd(ids, de, vocab):
     return dword
 
 
+def text_key_mask(att):
+    """int64 attention mask [B, L] -> DistilBERT's additive key mask, fp32 [B, L]: 0 for real tokens, -inf for padding (one launch)."""
+    B, L = att.shape
+    mask = torch.empty((B, L), device=att.device, dtype=torch.float32)
+    call("dvlp_text_key_mask", B, L, p(att), p(mask), stream())
+    return mask
+
+
 def text_mask_len(att):
     """(text_length int64 [B], text_mask fp32 [B, L - 1]) = (att.sum(1), (att[:, 1:] - 1.0) * 100.0) in one launch (att: int64 [B, L] on the device)."""
     B, L = att.shape

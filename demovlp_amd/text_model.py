@@ -146,8 +146,12 @@ class DistilBertEncoder(nn.Module):
         B, L = input_ids.shape
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        addmask = torch.zeros((B, L), device=input_ids.device, dtype=torch.float32)
-        addmask.masked_fill_(attention_mask == 0, float("-inf"))
+        if attention_mask.is_cuda and attention_mask.dtype == torch.int64 and attention_mask.is_contiguous():
+            from . import ops
+            addmask = ops.text_key_mask(attention_mask)           # one launch (a fill, a comparison and a masked fill otherwise)
+        else:
+            addmask = torch.zeros((B, L), device=input_ids.device, dtype=torch.float32)
+            addmask.masked_fill_(attention_mask == 0, float("-inf"))
         e = self.embeddings
         c = self.config
         dropping = self.training and (c.dropout > 0.0 or c.attention_dropout > 0.0)

@@ -1027,7 +1027,8 @@ class GraphedTrainStep:
             self.opt.replayed()
         else:
             self._run_pieces(None, self.graphs)
-        return tuple(t.clone() for t in self.out)            # fresh tensors, like the eager step: a later replay must not rewrite them
+        # fresh tensors, like the eager step (a later replay must not rewrite them): one launch for the three scalars, not three copies
+        return tuple(torch.stack([t.reshape(()) for t in self.out]).unbind(0))
 
 
 def evaluate(model, loss_fn, batches, metrics=None, use_local=True, mscoco=False, log=None, precision=None):

@@ -157,6 +157,9 @@ int dvlp_cast(int src_dtype, int dst_dtype, int64_t n, const void* src, void* ds
 /* the loss' caption-side inputs from the attention mask in one launch (trainer/trainer_dist.py:152-159): text_length[b] = sum_w att[b][w] (int64)
    and text_mask[b][w - 1] = (att[b][w] - 1) * 100, w = 1 .. L - 1 (fp32 [B, L - 1]); att int64 [B, L] */
 int dvlp_text_mask_len(int64_t B, int64_t L, const int64_t* att, int64_t* text_length, float* text_mask, void* stream);
+/* DistilBERT's additive key mask (HF: scores.masked_fill(attention_mask == 0, -inf); call site model/model.py:87): key_mask[B][L] fp32 = 0 where
+   att != 0, -inf elsewhere -- one launch instead of a fill, a comparison and a masked fill */
+int dvlp_text_key_mask(int64_t B, int64_t L, const int64_t* att, float* key_mask, void* stream);
 
 /* ---- dropout of the text tower: the reference keeps DistilBERT in train mode (model/model.py:29-30), so HuggingFace's three
  *      dropouts (embeddings, attention probabilities, feed-forward output; p = 0.1) are part of every training step.  Masks are

@@ -27,8 +27,9 @@ int dvlp_dev_gemm_wide_mode(int mode);
 /* 256 x 256 ping-pong kernel (8 waves, counted-vmcnt LDS-DMA prefetch): 0 never, 1 where the grid suits it, 2 whenever the
    operands allow -- for A/B measurements and tests */
 int dvlp_dev_gemm_p8_mode(int mode);
-/* tile height of that kernel: 224-row tiles (the upper half of a tile 96 rows instead of 128) where they fill the CUs' rounds better than
-   256-row ones -- 0 never, 1 (default) where rounds x rows is smaller, 2 whenever the operands allow; for A/B measurements and tests */
+/* tile height / K split of that kernel: 1 (default) height 160 / 192 / 224 / 256 and split chosen together by the fitted cost model
+   (p8_plan); 0 always 256 rows; 2 224 rows whenever the operands allow; 3 round 5's rule (224 where rounds x rows is smaller, the old split);
+   10 + MIH a forced height (128 + 32 MIH rows) -- for A/B measurements (tools/tile_sweep.py) and tests */
 int dvlp_dev_gemm_p8_short_tiles(int mode);
 /* persistent form of that kernel on outputs of more than one round of tiles (one workgroup per CU walks its tiles; the next tile's first
    units are staged by the previous tile's last phases, the epilogue's stores are not waited for): 0 (default) off, 1 on -- for A/B
@@ -37,6 +38,9 @@ int dvlp_dev_gemm_p8_persistent(int mode);
 /* grouped weight gradients: 1 (default) blocks are dealt to the XCDs as 3 x 3 tile patches of one K slice, so a patch's operand panels are
    fetched into that XCD's L2 once; 0: per-problem tile order -- for A/B measurements */
 int dvlp_dev_wgrad_group_patches(int on);
+/* batched skinny products (N, K <= 288, M in the thousands: the local loss' per-video / per-caption contractions) on the resident-B streaming
+   kernel (csrc/gemm_rb.hip): 1 (default) where its shapes fit, 0 never -- for A/B measurements and tests */
+int dvlp_dev_gemm_resident_b(int on);
 /* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
 int dvlp_dev_gemm_splitk_target(int64_t n);
 /* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the

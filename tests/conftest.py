@@ -18,6 +18,9 @@ def pytest_addoption(parser):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from rows import ALL_ROWS
+    for r in ALL_ROWS:
+        config.addinivalue_line("markers", f"row_{r}: covers SURVEY.md section-8 row {r} (tests/rows.py)")
     config.addinivalue_line("markers", "devlib: the test forces a code path through a dvlp_dev_* switch and therefore runs on libdemovlp_hip_dev.so (set automatically)")
     config.addinivalue_line("markers", "slow: long second variant of a two-process GPU test; skipped unless --runslow")
 
@@ -62,9 +65,12 @@ def _item_uses_dev_switches(item):
 def pytest_collection_modifyitems(config, items):
     # tests that force a code path through a developer switch run on libdemovlp_hip_dev.so (the product library exports none);
     # everything else -- the parity tests proper -- stays on libdemovlp_hip.so
+    from rows import rows_of
     for item in items:
         if _item_uses_dev_switches(item):
             item.add_marker(pytest.mark.devlib)
+        for r in rows_of(getattr(item, "originalname", None) or item.name.split("[")[0]):
+            item.add_marker(getattr(pytest.mark, "row_" + r))
     if config.getoption("--runslow"):
         return
     skip = pytest.mark.skip(reason="slow variant: run with --runslow")

@@ -320,9 +320,43 @@ def _xattn_case(dtype, Bi, Bj, G, W, gate):
     dsc = torch.from_numpy(rng.standard_normal((Bi, Bj)).astype(np.float32))
     ref.backward(dsc.double())
     dC, dQ = ops.xattn_bwd(C, Q, mi, mc, 20.0, gate, dsc.to(DEV), ws)
-    tg = 5e-3 if dtype == torch.float32 else 1e-1
-    assert float((dC.double().cpu() - Cr.grad).abs().max()) < tg * float(Cr.grad.abs().max())
-    assert float((dQ.double().cpu() - Qr.grad).abs().max()) < tg * float(Qr.grad.abs().max())
+    # fp32 against the float64 reference: round 6 measured the deviations (printed with -s) and tightened the bar from 5e-3 to 5e-4 of max|grad|
+    tg = 5e-4 if dtype == torch.float32 else 1e-1
+    eC = float((dC.double().cpu() - Cr.grad).abs().max()) / float(Cr.grad.abs().max())
+    eQ = float((dQ.double().cpu() - Qr.grad).abs().max()) / float(Qr.grad.abs().max())
+    print("\nxattn %s Bi=%d Bj=%d G=%d W=%d gate=%s: scores %.2e, dC %.2e, dQ %.2e of max|ref| (fp64 reference)" % (str(dtype)[6:], Bi, Bj, G, W, gate, rel(scores, ref), eC, eQ))
+    assert eC < tg and eQ < tg, (eC, eQ)
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(6656, 256, 288, 1), (6656, 288, 256, 0), (18432, 104, 104, 0), (2100, 256, 240, 1), (5001, 240, 256, 0), (3000, 96, 72, 0)])
+def test_gemm_resident_b_batched_against_the_tile_kernel_and_fp32(M, N, K, tb):
+    """csrc/gemm_rb.hip (round 6): the local loss' batched skinny products (wc = P1 C^, dP1 = dwc C^T, T = P2 Kq and their R = 30 / ragged
+    variants) with the whole B operand resident in LDS and A streamed in fragment shape.  Against the fp32 product (bf16 output rounding)
+    and against the 128 x 128 tile kernel it replaces (same operands, same fp32 accumulation up to summation order: equal to 1 bf16 ulp);
+    a strided A (lda > K) and rows beyond M must be left untouched."""
+    nb = 9
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    lda = K + 16
+    A = torch.randn(nb, M, lda, device=DEV, generator=g).bfloat16()
+    B = (torch.randn((nb, K, N) if tb else (nb, N, K), device=DEV, generator=g) * 0.3).bfloat16()
+    ref = torch.bmm(A[:, :, :K].float(), B.float() if tb else B.float().transpose(1, 2))
+
+    def run(rb):
+        ops.call("dvlp_dev_gemm_resident_b", rb)
+        C = torch.full((nb, M + 3, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.ensure_gemm_workspace(A.device)
+        ops.call("dvlp_gemm_batched", ops.BF16, 0, tb, M, N, K, ops.p(A), lda, ops.p(B), N if tb else K, ops.p(C), N, None, None, 0, None, 0, 0, 1.0, nb,
+             M * lda, B[0].numel(), (M + 3) * N, 0, 0, ops.stream())
+        return C
+    try:
+        new, old = run(1), run(0)
+    finally:
+        ops.call("dvlp_dev_gemm_resident_b", 1)
+    assert bool((new[:, M:] == 7.0).all()) and bool((old[:, M:] == 7.0).all())            # nothing written beyond row M
+    scale = float(ref.abs().max())
+    assert float((new[:, :M].float() - ref).abs().max()) < 1e-2 * scale
+    assert float((new[:, :M].float() - old[:, :M].float()).abs().max()) <= 2.0 ** -7 * scale + 1e-6    # one bf16 ulp at the largest magnitude
+    assert float(((new[:, :M].float() - ref).abs().mean())) < 2e-3 * scale
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

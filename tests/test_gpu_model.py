@@ -85,8 +85,8 @@ def test_fp32_gradients_vs_float64_oracle(tag):
     """Gradient parity at the OUTPUT bar.  The 2e-3 bound above is against the reference's own fp32 gradients, which carry torch's fp32
     rounding noise (up to 6.9e-4 of a tensor's max against exact arithmetic: `reference_entry_deviation_worst` in the fixture).  G2b
     (tests/golden/make_f64_grads.py) holds the float64 gradients of the pinned oracle for the same inputs and weights: every gradient tensor
-    of the fp32 HIP path must lie within 2e-4 of its tensor's max|g| of them (all entries of tensors up to 4096 elements, 256 sampled
-    entries of the larger ones), its norm within 2e-4, and the analytically zero ones (DistilBERT's key biases: a key bias shifts every
+    of the fp32 HIP path must lie within 1e-4 of its tensor's max|g| of them (all entries of tensors up to 4096 elements, 256 sampled
+    entries of the larger ones), its norm within 1e-4, and the analytically zero ones (DistilBERT's key biases: a key bias shifts every
     score of a softmax row alike) below 1e-6 absolute."""
     g = load_golden(f"g2b_{tag}_f64grads.npz")
     F, R, B = int(g["F"]), int(g["R"]), int(g["B"])
@@ -97,7 +97,7 @@ def test_fp32_gradients_vs_float64_oracle(tag):
     loss.backward()
     named = dict(model.named_parameters())
     zero = set(str(z) for z in g["zero_grad_names"])
-    TOL = 2e-4
+    TOL = 1e-4           # measured on MI355X: worst entry 2.6e-5 of its tensor's max, worst norm 1.1e-5 (the reference's own fp32 gradients: 1.8e-5 .. 6.9e-4)
     worst = []
     for k, n, mx in zip(g["grad_names"], g["grad_norms"], g["grad_max"]):
         k = str(k)

@@ -66,13 +66,21 @@ def _spawn(target, args_of_rank, world=2, timeout=900):
     procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args_of_rank)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=timeout) for _ in procs], key=lambda t: t[0])
+    res = []
+    try:
+        for _ in procs:
+            r = q.get(timeout=timeout)
+            if isinstance(r[1], str):             # a rank failed: its peers are waiting in a collective that will never complete -- do not wait for them
+                raise AssertionError("rank %d failed:\n%s" % (r[0], r[1]))
+            res.append(r)
+    except BaseException:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        raise
     for p in procs:
         p.join(120)
-    for r in res:
-        if isinstance(r[1], str):
-            raise AssertionError("rank %d failed:\n%s" % (r[0], r[1]))
-    return res
+    return sorted(res, key=lambda t: t[0])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -282,7 +290,7 @@ def test_gather_negatives_two_ranks_on_device_vs_oracle():
     # forward graph ends at the local embeddings, the all-gather runs between two replays, the loss / backward graphs start from the gathered
     # buffers, the three-piece gradient exchange follows.  Its first two steps (eager warm-ups) and its replays must reproduce the eager
     # train_step sequence above; ranks bit-equal; a batch of another shape gets buffers of its own.
-    gres = _spawn(_graph_gather_worker, ())
+    gres = _spawn(_graph_gather_worker, (), timeout=400)
     for rank in range(2):
         _, gl, after2, pfin, info = gres[rank]
         eager = res[rank][3]

@@ -515,3 +515,26 @@ def test_no_undefined_names_anywhere_in_the_tree():
     assert len(files) > 40 and any(f.endswith("test_gpu_round3.py") for f in files)
     bad = [b for f in files for b in un.scan(f)]
     assert not bad, "\n".join("%s: %s: undefined name %r" % b for b in bad)
+
+
+def test_every_test_is_mapped_to_a_survey_row():
+    """tests/rows.py is the row-by-row index of the suite: every test function must name the row(s) it covers, every row
+    must be covered by at least one GPU test where it is a device path, and the map must not name functions that no longer exist."""
+    import ast
+    import glob
+    import rows
+    have = {}
+    for path in glob.glob(os.path.join(ROOT, "tests", "test_*.py")):
+        src = open(path).read()
+        gpu_file = any(line.startswith("pytestmark = pytest.mark.gpu") for line in src.splitlines())
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.FunctionDef) and node.name.startswith("test_"):
+                have.setdefault(node.name, []).append(gpu_file)
+    assert not sorted(set(have) - set(rows.ROWS)), "tests missing from tests/rows.py"
+    assert not sorted(set(rows.ROWS) - set(have)), "tests/rows.py names functions that do not exist"
+    assert all(set(v.split()) <= set(rows.ALL_ROWS) and v.split() for v in rows.ROWS.values())
+    for r in rows.ALL_ROWS:
+        fns = [f for f, v in rows.ROWS.items() if r in v.split()]
+        assert fns, r
+        if r not in ("b", "c"):                                      # every path row has at least one test that runs on the device
+            assert any(any(have[f]) for f in fns), r

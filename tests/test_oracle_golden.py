@@ -321,3 +321,25 @@ def test_float64_oracle_gradients_agree_with_the_reference(tag):
         k = "object_model.blocks.11.mlp.fc1.weight"
         got = p[k].grad.numpy().reshape(-1)[gb["gradidx/" + k]]
         assert np.abs(got - gb["gradval/" + k]).max() <= 1e-12 * max(1.0, np.abs(gb["gradval/" + k]).max())
+
+
+def test_oracle_first_finetune_step_vs_reference_g14():
+    """Golden G14 (BASELINE config 4 end to end: the imported reference fine-tunes 10 steps at F = 8, R = 30, B = 32 from the retrieval weights,
+    then validates on the 256-pair set).  The oracle's forward on the first training batch reproduces the reference's first-step losses at
+    either learning rate; the fixture's own consistency is checked (the fine-tune moved the metrics away from G11's; curves start equal);
+    the ten steps and the evaluation themselves are the GPU tests' business (tests/test_gpu_round4.py)."""
+    g, g11 = load_golden("g14_finetune_eval.npz"), load_golden("g11_retrieval.npz")
+    F, R, BS, FIRST = int(g["F"]), int(g["R"]), int(g["batch"]), int(g["first_train_pair"])
+    assert (F, R, BS, int(g["steps"])) == (8, 30, 32, 10) and FIRST == 256
+    assert np.array_equal(g["lr1e-5_curve"][0], g["lr2e-4_curve"][0]) and not np.array_equal(g["lr1e-5_curve"][1], g["lr2e-4_curve"][1])
+    for tag in ("lr1e-5", "lr2e-4"):
+        assert g[tag + "_o2t_sims"].shape == (256, 256) and g[tag + "_val_losses"].shape == (8, 3)
+        assert not np.array_equal(g[tag + "_t2v"], g11["t2v"]) or not np.array_equal(g[tag + "_v2t"], g11["v2t"])
+    sd = syn.retrieval_state_dict(F, R)
+    obj, mask, ids, att = syn.retrieval_batch(sd, F, R, FIRST, BS)
+    p = orc.params_from_numpy(sd)
+    with torch.no_grad():
+        out = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask))
+        tm = (torch.from_numpy(att)[:, 1:].float() - 1.0) * 100.0
+        got = np.array([x.item() for x in orc.global_local_loss(out, tm, batched=True)[:3]])
+    assert np.abs(got - g["lr1e-5_curve"][0]).max() < 2e-4 * g["lr1e-5_curve"][0, 0], (got, g["lr1e-5_curve"][0])

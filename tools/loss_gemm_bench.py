@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from demovlp_amd import _lib, ops  # noqa: E402
+_lib.use_dev_library()     # developer switches (dvlp_dev_*) exist only in libdemovlp_hip_dev.so
 
 lib = _lib.load()
 dev = "cuda"
@@ -51,8 +52,11 @@ for label, ta, tb, M, N, K, nb in shapes:
 
     def stock():
         torch.bmm(Am, Bm, out=C)
+    lib.dvlp_dev_gemm_resident_b(0)
+    t0 = bench(ours)                  # the tile kernels (round 5's path)
+    lib.dvlp_dev_gemm_resident_b(1)
     t1, t2 = bench(ours), bench(stock)
     byts = 2.0 * nb * (M * K + N * K + M * N)
     fl = 2.0 * nb * M * N * K
-    print(f"{label}  M={M:6d} N={N:5d} K={K:6d} b={nb:3d}   ours {t1:7.1f} us ({fl / t1 / 1e6:5.0f} TF, {byts / t1 / 1e6:5.2f} TB/s)   stock {t2:7.1f} us ({fl / t2 / 1e6:5.0f} TF)"
+    print(f"{label}  M={M:6d} N={N:5d} K={K:6d} b={nb:3d}   tile kernel {t0:7.1f} us   ours {t1:7.1f} us ({fl / t1 / 1e6:5.0f} TF, {byts / t1 / 1e6:5.2f} TB/s)   stock {t2:7.1f} us ({fl / t2 / 1e6:5.0f} TF)"
           f"   HBM bound {byts / 5e6:6.1f} us")
