@@ -452,6 +452,8 @@ def main():
             "step_model_tflops": round(value * fpp / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * fpp / 1e12 / (peak * world), 4),
         }
+        if getattr(ops, "LN_FWD_ABLATE", False):
+            out["INVALID_timing_only_ablation"] = "DVLP_ABLATE_LN_FWD=1: forward LayerNorm passes skipped (results wrong): an upper bound for LayerNorm fusion, not a throughput figure"
         if per_rank is not None:
             out["per_rank_pairs_per_s"] = per_rank
             out["grad_allreduce_ms_standalone"] = allreduce_ms

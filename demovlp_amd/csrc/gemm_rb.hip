@@ -85,10 +85,12 @@ __global__ __launch_bounds__(512) void gemm_rb_kernel(RbArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            // (scheduling fences per half k-step: left alone, the compiler hoists all NB x KS panel reads above the products and spills ~400 registers)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const bf16x8 bf = *(const bf16x8*)(prow + nb * 16 * LDK + s * 32);
                 acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, cur[s], acc[nb], 0, 0, 0);      // C^T: D[n = 16 nb + 4 lq + r][m = lc]
+                if ((nb & 7) == 7 || nb == NB - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // store: lane (lc, lq) holds C[m = lc][16 nb + 4 lq + r]; pair blocks (2 h, 2 h + 1) -> 8 consecutive columns per lane

@@ -333,8 +333,20 @@ def colsum_grouped(x, M, N, ld, inner, ostride, groups, gstride, out=None):
 # ----------------------------------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------------------------------
+# TIMING-ONLY ablation (DVLP_ABLATE_LN_FWD=1, tools/ln_fusion_bound.sh): the forward LayerNorm launches nothing and hands its INPUT on as its
+# output -- what the step would take if every forward LayerNorm pass were free, i.e. an upper bound on what any fusion of the normalisation
+# into a neighbouring product could buy in the step.  Results are wrong by construction; bench.py marks the line.
+LN_FWD_ABLATE = bool(int(__import__("os").environ.get("DVLP_ABLATE_LN_FWD", "0")))
+_LN_ABL = {}
+
+
 def layernorm_fwd(x2d, gamma, beta, eps, want_relu=False):
     M, D = x2d.shape
+    if LN_FWD_ABLATE and not want_relu:
+        key = (M, str(x2d.device))
+        if key not in _LN_ABL:                      # constant statistics (mean 0, rstd 1), allocated once: no launch per call
+            _LN_ABL[key] = (torch.zeros(M, device=x2d.device, dtype=torch.float32), torch.ones(M, device=x2d.device, dtype=torch.float32))
+        return x2d, None, _LN_ABL[key][0], _LN_ABL[key][1]
     y = torch.empty_like(x2d)
     yr = torch.empty_like(x2d) if want_relu else None
     mean = torch.empty(M, device=x2d.device, dtype=torch.float32)

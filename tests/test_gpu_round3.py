@@ -223,8 +223,11 @@ def _gather_worker(rank, world, port, q, with_step):
 def _graph_gather_worker(rank, world, port, q):
     """GraphedTrainStep(gather_negatives=args): forward graph -> all-gather outside the graphs -> loss / backward graphs + bucketed gradient exchange."""
     import argparse
+    import faulthandler
+    import sys
     import traceback
     import torch.distributed as dist
+    faulthandler.dump_traceback_later(150, exit=True, file=sys.stderr)        # a rank stuck in a collective must say where (and end) instead of timing the test out
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -248,6 +251,7 @@ def _graph_gather_worker(rank, world, port, q):
         losses.append([float(t.item()) for t in stepper(data)])
         torch.cuda.synchronize()
         info = dict(graphs=len(stepper.graphs or ()), sets=len(stepper._sets), steps=opt.step_count, gbufs=len(stepper._gbufs))
+        faulthandler.cancel_dump_traceback_later()
         q.put((rank, losses, after2, arena.flat_p.double().cpu().numpy()[::211], info))
     except BaseException:  # noqa: BLE001
         q.put((rank, traceback.format_exc()))
@@ -290,7 +294,7 @@ def test_gather_negatives_two_ranks_on_device_vs_oracle():
     # forward graph ends at the local embeddings, the all-gather runs between two replays, the loss / backward graphs start from the gathered
     # buffers, the three-piece gradient exchange follows.  Its first two steps (eager warm-ups) and its replays must reproduce the eager
     # train_step sequence above; ranks bit-equal; a batch of another shape gets buffers of its own.
-    gres = _spawn(_graph_gather_worker, (), timeout=400)
+    gres = _spawn(_graph_gather_worker, (), timeout=240)
     for rank in range(2):
         _, gl, after2, pfin, info = gres[rank]
         eager = res[rank][3]

@@ -138,7 +138,11 @@ def _finetune_then_eval(dtype, lr, g):
 
 
 # measured on MI355X (printed by the tests), bounds = 2-3x the observation
-G14_FP32 = {"lr1e-5": dict(curve=2e-4, sims=1e-3), "lr2e-4": dict(curve=5e-3, sims=3e-2)}
+# lr 1e-5: curve 1.1e-5 of the loss, similarities 8.6e-4 (Adam turns fp32 rounding noise on near-zero gradients into +-lr moves: the weights
+# after ten steps agree to ~1e-5, the similarity matrix built from them to 1e-3), 0 / 10 of 256 ranks moved (all among the queries the reference
+# decides by less than twice that).  lr 2e-4 is CHAOTIC on this set: the reference's own curve climbs 15.84 -> 16.08 over its last five steps, two
+# fp32 implementations part by 7e-3 of the loss after ten steps and their similarity matrices by 0.5 -- only the first steps are comparable.
+G14_FP32 = {"lr1e-5": dict(curve=1e-4, sims=4e-3), "lr2e-4": dict(curve=3e-2, sims=None, first=(4, 2e-3))}
 
 
 @pytest.mark.parametrize("tag,lr", [("lr1e-5", 1e-5), ("lr2e-4", 2e-4)])
@@ -157,6 +161,14 @@ def test_fp32_finetune_then_evaluate_vs_reference(tag, lr):
     print("\nG14 %s fp32: loss curve dev %.2e of the loss (first %.4f -> last %.4f; reference %.4f -> %.4f); o2t sims max dev %.2e (max |sim| %.2f); val loss %.4f vs %.4f"
           % (tag, dc, curve[0, 0], curve[-1, 0], ref[0, 0], ref[-1, 0], dev, np.abs(sims).max(), res["val_loss"], g[tag + "_val_losses"][:, 0].mean()))
     assert dc < G14_FP32[tag]["curve"], dc
+    if "first" in G14_FP32[tag]:                       # the chaotic learning rate: the first steps must still agree closely
+        k, tol = G14_FP32[tag]["first"]
+        d0 = np.abs(curve[:k] - ref[:k]).max() / np.abs(ref[:k, 0]).max()
+        print("   first %d steps: %.2e of the loss" % (k, d0))
+        assert d0 < tol, d0
+    if G14_FP32[tag]["sims"] is None:
+        assert np.isfinite(res["o2t_sims"]).all() and abs(res["val_loss"] - g[tag + "_val_losses"][:, 0].mean()) < 0.05 * g[tag + "_val_losses"][0, 0]
+        return
     assert dev < G14_FP32[tag]["sims"] * max(1.0, np.abs(sims).max()), dev
     assert abs(res["val_loss"] - g[tag + "_val_losses"][:, 0].mean()) < 10 * G14_FP32[tag]["curve"] * g[tag + "_val_losses"][0, 0]
     for name, axis in (("t2v", 1), ("v2t", 0)):
