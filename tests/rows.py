@@ -58,16 +58,19 @@ ROWS = {
     "test_oracle_first_finetune_step_vs_reference_g14": "c A14 f1",
     # ---- tests/test_gpu_kernels.py
     "test_gemm_forward_forms": "A3 A5 A6 A8",
+    "test_gemm_forward_forms_every_tile_variant": "A3 A5 A6 A8",
     "test_gemm_epilogues": "A5 A3",
     "test_layernorm": "A3 A8",
     "test_colsum": "A3 A14",
     "test_space_attention": "A4",
+    "test_space_attention_other_backward_forms": "A4",
     "test_space_attention_round5_kernels_against_the_round4_kernels": "A4",
     "test_space_attention_fold_switched_off": "A4",
     "test_full_attention": "A8",
     "test_object_prologue_pieces": "A2",
     "test_text_embed": "A8",
     "test_xattn": "A10",
+    "test_xattn_long_video_path_forced_on_shapes_the_pair_kernels_also_take": "A10",
     "test_loss_heads": "A9 A11",
     "test_split_cls_forward_and_backward_equal_the_slicing_form": "A7",
     "test_loss_heads_matrix_core_form": "A9 A11",

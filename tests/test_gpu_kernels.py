@@ -46,9 +46,24 @@ def wide_mode(request):
     ops.call("dvlp_dev_gemm_p8_mode", P8_DEFAULT)
 
 
+GEMM_SHAPES = [(578, 768, 768), (300, 200, 104), (128, 128, 64), (1, 256, 768), (130, 2304, 768), (1000, 384, 1280)]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(578, 768, 768), (300, 200, 104), (128, 128, 64), (1, 256, 768), (130, 2304, 768), (1000, 384, 1280)])
-def test_gemm_forward_forms(dtype, M, N, K, wide_mode):
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(6400, 768, 768), (6400, 768, 3072), (7712, 3072, 768)])
+def test_gemm_forward_forms(dtype, M, N, K):
+    """nn.Linear forward / dX / dW through the PRODUCT library's own dispatch (incl. the text tower's and config 4's token counts, where round 6's
+    planner picks 160 / 192-row tiles and a 2-way K split)."""
+    _gemm_forms_case(dtype, M, N, K)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_forward_forms_every_tile_variant(dtype, M, N, K, wide_mode):
+    _gemm_forms_case(dtype, M, N, K)
+
+
+def _gemm_forms_case(dtype, M, N, K):
     a, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, seed=1)
     ref = a.float() @ w.float().t()
     y = ops.gemm(a, w, M, N, K)
@@ -146,9 +161,27 @@ def attn_bwd_variant(request):
     ops.call("dvlp_dev_attention_bwd_variant", 1)
 
 
+ATTN_SHAPES = [(2, 8, 36), (3, 1, 30), (1, 32, 36), (2, 8, 30), (2, 4, 15), (2, 3, 47), (1, 2, 50)]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,F,R", [(2, 8, 36), (3, 1, 30), (1, 32, 36), (2, 8, 30), (2, 4, 15), (2, 3, 47), (1, 2, 50)])
-def test_space_attention(dtype, B, F, R, attn_bwd_variant):
+@pytest.mark.parametrize("B,F,R", ATTN_SHAPES)
+def test_space_attention(dtype, B, F, R):
+    """VarAttention (model/object_transformer.py:152-196) against the oracle through the PRODUCT library's dispatch: the CLS query folded into the
+    frame waves forward and backward, the forward's statistics handed to the backward -- what VitBlockFn runs."""
+    _space_attention_case(dtype, B, F, R, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,F,R", ATTN_SHAPES)
+def test_space_attention_other_backward_forms(dtype, B, F, R, attn_bwd_variant):
+    """The one-pass backward with its own statistics launch and the three-launch backward (developer switch), same bar."""
+    if attn_bwd_variant == 2:
+        pytest.skip("the default form runs on the product library: test_space_attention")
+    _space_attention_case(dtype, B, F, R, attn_bwd_variant)
+
+
+def _space_attention_case(dtype, B, F, R, attn_bwd_variant):
     N = 1 + F * R
     qkv = rnd(B * N, 2304, dtype=dtype, scale=1.5)
     mask01 = (torch.rand(B, N - 1, generator=torch.Generator().manual_seed(1)) > 0.2).float()
@@ -284,16 +317,21 @@ def test_text_embed(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Bi,Bj,G,W,gate,general", [(2, 2, 288, 99, True, False), (3, 4, 240, 99, True, False), (2, 3, 30, 99, True, False),
-                                                      (3, 3, 64, 17, False, False), (2, 2, 1152, 99, True, False),
-                                                      (2, 3, 288, 99, True, True), (3, 2, 30, 99, False, True),
-                                                      (1, 3, 288, 99, True, False), (2, 1, 72, 99, True, False), (1, 1, 36, 8, True, False)])
-def test_xattn(dtype, Bi, Bj, G, W, gate, general):
-    """general=True forces the long-video (general-G) softmax path on shapes the fused kernels also handle; G=1152 takes it
-    by itself (the [G, W] tile no longer fits LDS)."""
-    ops.call("dvlp_dev_xattn_force_general", int(general))
+@pytest.mark.parametrize("Bi,Bj,G,W,gate", [(2, 2, 288, 99, True), (3, 4, 240, 99, True), (2, 3, 30, 99, True), (3, 3, 64, 17, False), (2, 2, 1152, 99, True),
+                                              (1, 3, 288, 99, True), (2, 1, 72, 99, True), (1, 1, 36, 8, True)])
+def test_xattn(dtype, Bi, Bj, G, W, gate):
+    """The local loss' score matrix and its gradients against the float64 oracle, through the PRODUCT library's own dispatch (G = 1152 takes
+    the chunked long-video path by itself: the [G, W] tile no longer fits LDS)."""
+    _xattn_case(dtype, Bi, Bj, G, W, gate, general=G > 288)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Bi,Bj,G,W,gate", [(2, 3, 288, 99, True), (3, 2, 30, 99, False)])
+def test_xattn_long_video_path_forced_on_shapes_the_pair_kernels_also_take(dtype, Bi, Bj, G, W, gate):
+    """dvlp_dev_xattn_force_general (developer library): the chunked general-G softmax path on shapes the per-pair kernels handle too."""
+    ops.call("dvlp_dev_xattn_force_general", 1)
     try:
-        _xattn_case(dtype, Bi, Bj, G, W, gate, general)
+        _xattn_case(dtype, Bi, Bj, G, W, gate, general=True)
     finally:
         ops.call("dvlp_dev_xattn_force_general", 0)
 

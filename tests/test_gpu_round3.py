@@ -239,7 +239,25 @@ def _graph_gather_worker(rank, world, port, q):
         data = to_dev(*_np_batch(F, R, B, rank, 0))
         stepper = GraphedTrainStep(model, loss_head(), opt, warmup=2, gather_negatives=args)
         losses, after2 = [], None
+        dbg = os.environ.get("DVLP_GATHER_DEBUG")
+
+        def mark(msg):
+            if dbg:
+                with open(os.path.join(dbg, "gather_rank%d.log" % rank), "a") as fh:
+                    fh.write(msg + "\n")
+        if dbg:                      # where does a rank stop?  (developer aid: DVLP_GATHER_DEBUG=<dir>)
+            import demovlp_amd.trainer as T
+            for name in ("_piece", "_gather", "_exchange_and_update", "_capture", "_begin_updates", "_end_updates"):
+                orig = getattr(T.GraphedTrainStep, name)
+
+                def wrap(self_, *a, _o=orig, _n=name, **k):
+                    mark("enter %s %s" % (_n, a[0] if a and isinstance(a[0], int) else ""))
+                    r = _o(self_, *a, **k)
+                    mark("leave %s" % _n)
+                    return r
+                setattr(T.GraphedTrainStep, name, wrap)
         for s in range(5):                                   # 2 eager warm-ups, the capturing call, 2 replays
+            mark("step %d" % s)
             losses.append([float(t.item()) for t in stepper(data)])
             if s == 1:
                 torch.cuda.synchronize()

@@ -138,7 +138,13 @@ if os.path.exists(f32):
     l32 = [l for l in open(f32) if l.startswith("{")]
     if l32:
         open(os.path.join(P, tag + "_bench_f32_b16.json"), "w").write(l32[-1])
-for extra in ("select_bench.txt", "select_bench_f32.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt",
+for jf in ("bench_f8_r30_b32.json", "ln_fusion_bound.json"):        # config 4's shape (B = 32, F = 8, R = 30); the timing-only LayerNorm-forward ablation
+    src = os.path.join(SRC, jf)
+    if os.path.exists(src):
+        lj = [l for l in open(src) if l.startswith("{")]
+        if lj:
+            open(os.path.join(P, tag + "_" + jf), "w").write(lj[-1])
+for extra in ("tile_sweep.txt", "loss_gemm_bench.txt", "select_bench.txt", "select_bench_f32.txt", "xfused_check.txt", "xloss_bench.txt", "epi_bench.txt", "lib_gemm_ref.txt", "gemm_shapes.txt",
               "input_bench.txt", "eval_bench.txt", "tile_height_bench.txt", "attn_bench.txt", "loss_head_bench.txt", "step_timeline.txt"):
     src = os.path.join(SRC, extra)
     if os.path.exists(src):

@@ -31,6 +31,13 @@ timeout 300 python3 $R/tools/lib_gemm_ref.py > $O/lib_gemm_ref.txt 2>&1
 DVLP_PROF_REPORT=1 timeout 300 python3 $R/bench.py --no-cpu-baseline --no-object-tower --steps 10 --warmup 3 2>&1 | grep "kern=" | sort > $O/gemm_shapes.txt
 # config 5 (32-frame long-video variant, B = 16 per GPU): one bench line and K1 at F = 32; the input side (host staging + PCIe + select)
 timeout 600 python3 $R/bench.py --frames 32 --batch 16 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_f32_b16.json 2> $O/bench_f32.err
+# config 4 (configs/ft/msrvtt_o2t-select.json geometry: F = 8, R = 30, per-GPU batch 32 -> 7712 tokens): its own throughput line
+timeout 600 python3 $R/bench.py --batch 32 --regions 30 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f8_r30_b32.json 2> $O/bench_c4.err
+# TIMING-ONLY: what the step would take if every forward LayerNorm pass were free (an upper bound for fusing LayerNorm into a neighbouring product)
+DVLP_ABLATE_LN_FWD=1 timeout 600 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/ln_fusion_bound.json 2> $O/ln_bound.err
+# (tile height, K split) sweep of the 256-column kernel on the text tower's, config 4's and the object tower's shapes; the local loss' contractions
+(timeout 400 python3 $R/tools/tile_sweep.py text; timeout 300 python3 $R/tools/tile_sweep.py c4; timeout 400 python3 $R/tools/tile_sweep.py obj) > $O/tile_sweep.txt 2>&1
+timeout 300 python3 $R/tools/loss_gemm_bench.py > $O/loss_gemm_bench.txt 2>&1
 SELECT_F=32 SELECT_B=16 timeout 300 python3 $R/tools/select_bench.py > $O/select_bench_f32.txt 2>&1
 timeout 300 python3 $R/tools/input_bench.py > $O/input_bench.txt 2>&1
 timeout 900 python3 $R/tools/eval_bench.py --pairs 1000 > $O/eval_bench.txt 2>&1
