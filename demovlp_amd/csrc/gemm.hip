@@ -1491,6 +1491,24 @@ static WsEntry ws_for(void* stream) {
     return it == g_ws_map.end() ? WsEntry{nullptr, 0} : it->second;
 }
 
+// Per-stream hint (caller-registered, like the workspaces): launches on `stream` share the chip with another stream's kernels -- the text
+// tower beside the object tower (model.ObjectRelation.parallel_towers).  A co-running launch is not helped by finishing its own grid in fewer
+// rounds (the other stream fills the CUs it leaves idle); what counts is CU-time per FLOP, i.e. the tallest tiles: the dispatch then keeps round
+// 5's rule (256 / 224 rows, 3-way split of the text tower's K >= 2304 products) instead of the latency planner (p8_plan).  Measured in the
+// replayed step, same box, alternating runs: planner on the co-running text tower 17.72 / 17.72 ms against 17.59 / 17.63 with this rule;
+// single stream 18.88 / 18.92 with the planner against 18.99 / 19.02 without (profiles/r6_planner_ab.txt).
+static std::unordered_map<void*, int> g_stream_hint;
+extern "C" int dvlp_stream_hint(void* stream, int co_running) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (co_running) g_stream_hint[stream] = co_running; else g_stream_hint.erase(stream);
+    return DVLP_OK;
+}
+static bool stream_co_running(void* stream) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_stream_hint.find(stream);
+    return it != g_stream_hint.end() && it->second != 0;
+}
+
 struct ProfRec { hipEvent_t a, b; double flops; int64_t M, N, K, batch; int form, flags, kern; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
@@ -1649,7 +1667,8 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         // (the text tower): 160-row tiles (120 / 480 blocks instead of 75 / 300), K >= 2304 as 160 rows x 2 slices instead of 256 x 3.
         int mih8 = 4;
         const bool plan8 = p8 && g_p8_short != 0 && !transA && batch == 1 && N % 256 == 0 && e.vec && (N & 3) == 0;
-        if (plan8 && g_p8_short == 1 && g_force_split == 0) {
+        const bool co_run = plan8 && g_p8_short == 1 && stream_co_running(stream);
+        if (plan8 && g_p8_short == 1 && g_force_split == 0 && !co_run) {
             const P8Plan pl = p8_plan(M, N, K, ntn8, ncu8, g_ws != nullptr && K >= 1024, g_ws_bytes);
             mih8 = pl.mih; S = pl.S;
         } else {
@@ -1663,7 +1682,7 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
             if (plan8) {           // developer switches: a forced height (10 + MIH), "224 wherever allowed" (2), round 5's rule (3)
                 if (g_p8_short >= 10) mih8 = g_p8_short - 10 >= 1 && g_p8_short - 10 <= 4 ? g_p8_short - 10 : 4;
                 else if (g_p8_short == 2) mih8 = 3;
-                else if (g_p8_short == 3 && S == 1 && cdiv(cdiv(M, 224) * ntn8, ncu8) * 224 < cdiv(tiles8, ncu8) * 256) mih8 = 3;
+                else if ((g_p8_short == 3 || co_run) && S == 1 && cdiv(cdiv(M, 224) * ntn8, ncu8) * 224 < cdiv(tiles8, ncu8) * 256) mih8 = 3;
             }
         }
         int64_t kchunk = cdiv(cdiv(K, S), H_BK) * H_BK;

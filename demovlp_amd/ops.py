@@ -156,6 +156,7 @@ def _drop_library_registrations():
             call("dvlp_set_workspace_stream", ctypes.c_void_p(key[1]), None, 0)
     _GEMM_WS.clear()
     _COLSUM_CNT.clear()
+    _HINTED.clear()
 
 
 _SIDE = {}
@@ -172,11 +173,19 @@ def side_stream(device=None):
 _TEXT = {}
 
 
+_HINTED = set()
+
+
 def text_stream(device=None):
-    """HIP stream the text tower runs on when the two towers run concurrently (model.ObjectRelation.parallel_towers)."""
+    """HIP stream the text tower runs on when the two towers run concurrently (model.ObjectRelation.parallel_towers).  Registered with the
+    library as CO-RUNNING (dvlp_stream_hint): its GEMMs share the chip with the object tower's, so the dispatch picks tiles for CU-time per
+    FLOP rather than for the latency of their own grid."""
     device = torch.cuda.current_device() if device is None else device
     if device not in _TEXT:
         _TEXT[device] = torch.cuda.Stream(device=device)
+    if device not in _HINTED:
+        call("dvlp_stream_hint", ctypes.c_void_p(_TEXT[device].cuda_stream), 1)
+        _HINTED.add(device)
     return _TEXT[device]
 
 

@@ -707,6 +707,12 @@ class GraphedTrainStep:
             except BaseException:
                 self.opt.abort_overlapped()
                 raise
+            finally:
+                # keep the forward's OUTPUT BUFFERS (the all-gather of the next replay reads them), not its autograd graph: a graph kept
+                # alive across steps keeps the parameters' AccumulateGrad nodes alive with the stream they were created on (the eager
+                # warm-up's), and the engine then ties that stream to the capture stream of the next capture -- the capture never ends
+                del gathered
+                self._fwd = ({key: t.detach() for key, t in out.items()}, tl.detach(), tm.detach())
             self.opt._adopt_stray_grads()
         else:
             backward_next(self.model)

@@ -51,6 +51,10 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
    host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
+/* Per-stream hint, caller-registered like the workspaces: co_running != 0 says that launches on `stream` share the chip with kernels of another
+   stream (the text tower beside the object tower, model.ObjectRelation.parallel_towers); the bf16 GEMM dispatch then favours CU-time per FLOP
+   (tall tiles) over the latency of its own grid.  0 removes the hint. */
+int dvlp_stream_hint(void* stream, int co_running);
 /* dvlp_gemm with optional extras, handed to the call that consumes them (NULL = none).  `colsum`: fp32 dst[N] = column sums of the stored
    output C -- e.g. the bias gradient of the Linear whose output gradient this product is (batch 1, not for fp32 outputs).  Fused into the
    256-row kernel's epilogue through the deferred-reduction queue where possible (final after dvlp_reduce_flush; colsum_fused = 1),
