@@ -161,3 +161,38 @@ static inline int dvlp_launch_status() {
     return DVLP_ERR_LAUNCH;
 }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+
+// One HF-AdamW pass over elements [0, n) by thread `tid` of `nthreads` (4 elements per thread and iteration; hyper = {lr, beta1, beta2, eps,
+// weight_decay, grad_scale, step, step_size} in device memory).  Shared by adamw_dev_kernel (csrc/optim.hip) and by the spare workgroups of the
+// grouped weight-gradient launch (csrc/gemm.hip: the previous layer's update rides on the CUs that launch leaves idle).
+__device__ __forceinline__ void adamw_dev_elements(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ hyper, bf16* __restrict__ shadow, int64_t tid, int64_t nthreads) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5], step_size = hyper[7];
+    for (int64_t i = tid * 4; i < n; i += nthreads * 4) {
+        if (i + 3 < n) {
+            float4 pp = *(float4*)(p + i), gg = *(const float4*)(g + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
+            float* P = (float*)&pp; float* G = (float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gr = G[j] * grad_scale;
+                M[j] = M[j] * b1 + gr * (1.f - b1);
+                V[j] = V[j] * b2 + gr * gr * (1.f - b2);
+                P[j] = P[j] - step_size * (M[j] / (sqrtf(V[j]) + eps));
+                if (wd > 0.f) P[j] = P[j] - P[j] * lr * wd;
+            }
+            *(float4*)(p + i) = pp; *(float4*)(m + i) = mm; *(float4*)(v + i) = vv;
+            if (shadow) { bf16x4 s; s[0] = (bf16)P[0]; s[1] = (bf16)P[1]; s[2] = (bf16)P[2]; s[3] = (bf16)P[3]; *(bf16x4*)(shadow + i) = s; }
+        } else {
+            for (int64_t k = i; k < n; ++k) {
+                const float gr = g[k] * grad_scale;
+                m[k] = m[k] * b1 + gr * (1.f - b1);
+                v[k] = v[k] * b2 + gr * gr * (1.f - b2);
+                float x = p[k] - step_size * (m[k] / (sqrtf(v[k]) + eps));
+                if (wd > 0.f) x = x - x * lr * wd;
+                p[k] = x;
+                if (shadow) shadow[k] = (bf16)x;
+            }
+        }
+    }
+}

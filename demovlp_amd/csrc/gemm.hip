@@ -1346,9 +1346,22 @@ struct P8Group {
     // streaming its own two (measured with FETCH_SIZE: 1.15 GB -> see profiles per ViT layer; 455 MB are unique)
     int npatch;
     unsigned char pp[P8G_MAXP], pz[P8G_MAXP], ptm[P8G_MAXP], ptn[P8G_MAXP], ppm[P8G_MAXP], ppn[P8G_MAXP];
+    // Round 6: an optimizer update riding on the CUs this launch leaves idle (a ViT layer's group is 216 blocks on 256 CUs): blocks
+    // [opt_blk0, opt_blk0 + opt_nblk) run one fused HF-AdamW pass over opt_n elements -- the PREVIOUS layer's weights, whose gradients
+    // were final before this launch -- instead of a launch of its own between two GEMM launches (dvlp_wgrad_grouped_ex).
+    int opt_blk0, opt_nblk;
+    int64_t opt_n;
+    float *opt_p, *opt_m, *opt_v;
+    const float *opt_g, *opt_hyper;
+    bf16* opt_shadow;
 };
 __global__ __launch_bounds__(512) void gemm_bf16_p8_group_kernel(P8Group g, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (g.opt_nblk > 0 && (int)blockIdx.x >= g.opt_blk0) {            // a spare workgroup: its share of the riding optimizer update
+        adamw_dev_elements(g.opt_n, g.opt_p, g.opt_g, g.opt_m, g.opt_v, g.opt_hyper, g.opt_shadow,
+                           (int64_t)((int)blockIdx.x - g.opt_blk0) * 512 + threadIdx.x, (int64_t)g.opt_nblk * 512);
+        return;
+    }
     int p = 0, z;
     int64_t tm_, tn_;
     if (g.npatch > 0) {
@@ -1445,6 +1458,8 @@ DVLP_DEV_API int dvlp_dev_gemm_ablate(int bits) { g_ablate = bits; return DVLP_O
 static bool g_use_glds = true;
 static int g_wide_mode = 0;      // 0: never use the 256-row tile (default: measured no faster on this path's shapes), 1: heuristic, 2: always
 DVLP_DEV_API int dvlp_dev_gemm_wide_mode(int mode) { g_wide_mode = mode; return DVLP_OK; }
+static int g_wgrad_ride = 1;     // grouped weight gradients: 1 = an optimizer update handed to dvlp_wgrad_grouped_ex rides on the launch's spare workgroups, 0 = its own launch
+DVLP_DEV_API int dvlp_dev_wgrad_group_ride(int on) { g_wgrad_ride = on; return DVLP_OK; }
 static int g_wgrad_patch = 1;    // grouped weight gradients: 1 = 3 x 3 tile patches pinned to XCDs (operand panels shared through L2), 0 = per-problem tile order
 DVLP_DEV_API int dvlp_dev_wgrad_group_patches(int on) { g_wgrad_patch = on; return DVLP_OK; }
 static int g_p8_mode = 1;        // 256 x 256 ping-pong kernel: 0 never, 1 where the grid suits it, 2 whenever the operands allow
@@ -1672,7 +1687,10 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
             const P8Plan pl = p8_plan(M, N, K, ntn8, ncu8, g_ws != nullptr && K >= 1024, g_ws_bytes);
             mih8 = pl.mih; S = pl.S;
         } else {
-            if (g_ws && tiles < (p8 ? 128 : 200) && K >= 1024) {
+            // (a co-running launch is not split: slabs and a reduction launch buy latency it does not need with CU-time the other stream does --
+            //  DVLP_CORUN_SPLIT=1 restores the split for A/B runs)
+            static const bool corun_split = getenv("DVLP_CORUN_SPLIT") && atoi(getenv("DVLP_CORUN_SPLIT")) != 0;
+            if (g_ws && tiles < (p8 ? 128 : 200) && K >= 1024 && !(co_run && !corun_split)) {
                 S = p8 ? 256 / tiles : (g_splitk_target + tiles - 1) / tiles;
                 if (S > K / 256) S = K / 256;
                 if (S > 32) S = 32;
@@ -1790,9 +1808,40 @@ extern "C" int dvlp_gemm_ex(int dtype, int transA, int transB, int64_t M, int64_
 // Weight gradients of several linears in one go: dW_p[M_p, N_p] (fp32, contiguous) (+)= dY_p[K_p, M_p]^T X_p[K_p, N_p].
 // bf16 operands that suit the 256 x 256 kernel run as ONE grouped launch (+ one slab reduction); anything else falls back
 // to per-problem dvlp_gemm calls with identical results.
+// An HF-AdamW range update (dvlp_adamw_range_dev's arguments) handed to dvlp_wgrad_grouped_ex: run on the workgroups the grouped launch leaves
+// idle when there are at least 16 of them, else as a launch of its own right behind it.  `fused` (out): 1 = it rode along.
+struct dvlp_wgrad_ext {
+    int64_t n;
+    float* p; const float* g; float* m; float* v; const float* hyper; void* bf16_shadow;
+    int fused;
+};
+extern "C" int dvlp_adamw_range_dev(int64_t n, float* p, const float* g, float* m, float* v, const float* hyper, void* bf16_shadow, void* stream);
+
+static int wgrad_grouped_impl(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
+                              const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate,
+                              dvlp_wgrad_ext* ext, void* stream);
+
 extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                                   const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate,
                                   void* stream) {
+    return wgrad_grouped_impl(dtype, count, M, N, K, dY, ld_dy, X, ld_x, dW, accumulate, nullptr, stream);
+}
+extern "C" int dvlp_wgrad_grouped_ex(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
+                                     const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate,
+                                     dvlp_wgrad_ext* ext, void* stream) {
+    if (ext) {
+        ext->fused = 0;
+        if (ext->n <= 0 || !ext->hyper || (((uintptr_t)ext->p | (uintptr_t)ext->g | (uintptr_t)ext->m | (uintptr_t)ext->v) & 15) || ((uintptr_t)ext->bf16_shadow & 7))
+            return DVLP_ERR_SHAPE;
+    }
+    const int rc = wgrad_grouped_impl(dtype, count, M, N, K, dY, ld_dy, X, ld_x, dW, accumulate, ext, stream);
+    if (rc != DVLP_OK || !ext || ext->fused) return rc;
+    return dvlp_adamw_range_dev(ext->n, ext->p, ext->g, ext->m, ext->v, ext->hyper, ext->bf16_shadow, stream);     // no room in the launch: its own
+}
+
+static int wgrad_grouped_impl(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
+                              const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate,
+                              dvlp_wgrad_ext* ext, void* stream) {
     if (count <= 0) return DVLP_OK;
     const int flags = EPI_OUT_F32 | (accumulate ? EPI_ACCUM : 0);
     bool group_ok = dtype == DVLP_BF16 && g_p8_mode != 0 && g_use_glds && count <= P8G_MAX && count > 1;
@@ -1832,6 +1881,12 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
     // by the uniform split to one problem as a third K slice (108 tiles: S = 3,2,2,2 -> 252 blocks instead of 216) made the whole
     // launch SLOWER -- 403 us against 309 us for a ViT layer's four products, 166 against 122 for a DistilBERT layer's -- although
     // it shortens a third of the blocks: tools/wgrad_bench.py.  g_wgrad_split > 0 forces a split (A/B measurements).
+    // a co-running group (the text tower's, on its own stream beside the object tower: dvlp_stream_hint) is not split: whole-K blocks on fewer
+    // CUs cost less CU-time than twice the blocks plus slabs plus a reduction launch, and the other stream uses what is left
+    // (DVLP_CORUN_WGRAD_SPLIT=1 restores the split for A/B runs)
+    static const bool corun_wsplit = getenv("DVLP_CORUN_WGRAD_SPLIT") && atoi(getenv("DVLP_CORUN_WGRAD_SPLIT")) != 0;
+    if (!tails && !corun_wsplit && g_wgrad_split == 0 && stream_co_running(stream))
+        for (int p = 0; p < count; ++p) S[p] = 1;
     if (g_wgrad_split > 0)
         for (int p = 0; p < count; ++p) { S[p] = g_wgrad_split; if (S[p] > Km[p] / 256) S[p] = Km[p] / 256 > 0 ? Km[p] / 256 : 1; }
     // slabs for every split problem must fit the split-K workspace; otherwise split less
@@ -1914,6 +1969,19 @@ extern "C" int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const 
     }
     { static bool once = false; if (!once) { once = true;
         (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_TOTAL); } }
+    g.opt_nblk = 0;
+    if (ext && g_wgrad_ride) {
+        static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+        int spare = ncu - blk % ncu;                 // CUs the last round of GEMM blocks leaves idle (one workgroup per CU: 136 KB of LDS each)
+        if (spare == ncu) spare = 0;
+        if (spare > 64) spare = 64;                  // (a co-running, unsplit text-tower group leaves more than the update can use)
+        if (spare >= 16) {
+            g.opt_blk0 = blk; g.opt_nblk = spare; g.opt_n = ext->n;
+            g.opt_p = ext->p; g.opt_g = ext->g; g.opt_m = ext->m; g.opt_v = ext->v; g.opt_hyper = ext->hyper; g.opt_shadow = (bf16*)ext->bf16_shadow;
+            blk += spare;
+            ext->fused = 1;
+        }
+    }
     hipLaunchKernelGGL(gemm_bf16_p8_group_kernel, dim3((unsigned)blk), dim3(512), (size_t)P_LDS_TOTAL, st, g, (accumulate ? EPI_ACCUM : 0) | (g_ablate << 24));
     if (nred) hipLaunchKernelGGL(p8_group_reduce_kernel, dim3((unsigned)rblk), dim3(256), 0, st, r, accumulate);
     if (g_prof) { (void)hipEventRecord(rec.b, st); g_recs.push_back(rec); }

@@ -58,33 +58,7 @@ __global__ void adamw_prep_kernel(float* __restrict__ hyper) {
 }
 __global__ void adamw_dev_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  const float* __restrict__ hyper, bf16* __restrict__ shadow) {
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], grad_scale = hyper[5], step_size = hyper[7];
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
-        if (i + 3 < n) {
-            float4 pp = *(float4*)(p + i), gg = *(const float4*)(g + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
-            float* P = (float*)&pp; float* G = (float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float gr = G[j] * grad_scale;
-                M[j] = M[j] * b1 + gr * (1.f - b1);
-                V[j] = V[j] * b2 + gr * gr * (1.f - b2);
-                P[j] = P[j] - step_size * (M[j] / (sqrtf(V[j]) + eps));
-                if (wd > 0.f) P[j] = P[j] - P[j] * lr * wd;
-            }
-            *(float4*)(p + i) = pp; *(float4*)(m + i) = mm; *(float4*)(v + i) = vv;
-            if (shadow) { bf16x4 s; s[0] = (bf16)P[0]; s[1] = (bf16)P[1]; s[2] = (bf16)P[2]; s[3] = (bf16)P[3]; *(bf16x4*)(shadow + i) = s; }
-        } else {
-            for (int64_t k = i; k < n; ++k) {
-                const float gr = g[k] * grad_scale;
-                m[k] = m[k] * b1 + gr * (1.f - b1);
-                v[k] = v[k] * b2 + gr * gr * (1.f - b2);
-                float x = p[k] - step_size * (m[k] / (sqrtf(v[k]) + eps));
-                if (wd > 0.f) x = x - x * lr * wd;
-                p[k] = x;
-                if (shadow) shadow[k] = (bf16)x;
-            }
-        }
-    }
+    adamw_dev_elements(n, p, g, m, v, hyper, shadow, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 extern "C" int dvlp_adamw_step_dev(int64_t n, float* p, const float* g, float* m, float* v, float* hyper, void* bf16_shadow, void* stream) {

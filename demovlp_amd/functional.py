@@ -129,12 +129,16 @@ def _wgrad(dy2d, x2d, param):
 
 
 def _wgrad_group(items):
-    """Weight gradients of one layer [(dy2d, x2d, param | fp32 destination tensor), ...] as one grouped launch (ops.wgrad_grouped)."""
+    """Weight gradients of one layer [(dy2d, x2d, param | fp32 destination tensor), ...] as one grouped launch (ops.wgrad_grouped).  An
+    optimizer update left pending by the layer whose backward ran just before on this stream (``_early_update``) rides on the launch's
+    spare workgroups."""
     with _Side(*[t for it in items for t in it[:2]], level=2):
-        return ops.wgrad_grouped([(dy2d, x2d, _grad_buf(dst) if isinstance(dst, torch.nn.Parameter) else dst) for dy2d, x2d, dst in items])
+        ride = TAKE_PENDING_OPT() if TAKE_PENDING_OPT is not None else None
+        return ops.wgrad_grouped([(dy2d, x2d, _grad_buf(dst) if isinstance(dst, torch.nn.Parameter) else dst) for dy2d, x2d, dst in items], ride=ride)
 
 
 EARLY_OPT = None          # trainer.FusedAdamW.begin_overlapped installs its per-layer update here for the duration of one backward
+TAKE_PENDING_OPT = None   # ... and the hand-over of the update it left pending (to ride in the next grouped weight-gradient launch of the same stream)
 
 
 def _early_update(params):

@@ -228,9 +228,17 @@ def linear_bwd_weight(dy2d, x2d, out=None):
     return gemm(dy2d, x2d, N, K, M, trans_a=True, trans_b=True, lda=N, ldb=K, out=out, out_f32=True)
 
 
-def wgrad_grouped(problems):
+class WgradExt(ctypes.Structure):
+    """include/demovlp_hip.h: dvlp_wgrad_ext"""
+    _fields_ = [("n", ctypes.c_int64), ("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("hyper", ctypes.c_void_p), ("bf16_shadow", ctypes.c_void_p), ("fused", ctypes.c_int)]
+
+
+def wgrad_grouped(problems, ride=None):
     """[(dy2d [T, N_p], x2d [T, K_p], out fp32 [N_p, K_p] or None)] -> list of dW_p = dy_p^T x_p (fp32).  One grouped launch for
-    bf16 operands that suit the 256 x 256 GEMM kernel (a transformer layer's weight gradients), else per-problem GEMMs."""
+    bf16 operands that suit the 256 x 256 GEMM kernel (a transformer layer's weight gradients), else per-problem GEMMs.
+    ``ride``: (p, g, m, v, hyper, shadow | None, lo, hi) -- one fused-AdamW range update (adamw_range_dev's arguments) to be executed by the
+    workgroups the grouped launch leaves idle (dvlp_wgrad_grouped_ex); launched on its own right behind when there is no room."""
     n = len(problems)
     outs = []
     I64, VP = ctypes.c_int64 * n, ctypes.c_void_p * n
@@ -249,6 +257,13 @@ def wgrad_grouped(problems):
         outs.append(out)
         Ms[i], Ns[i], Ks[i], lda[i], ldb[i] = N, K, T, dy2d.stride(0), x2d.stride(0)
         A[i], Bp[i], C[i] = dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr()
+    if ride is not None:
+        fp, fg, fm, fv, hyper, shadow, lo, hi = ride
+        ext = WgradExt(n=hi - lo, p=fp.data_ptr() + 4 * lo, g=fg.data_ptr() + 4 * lo, m=fm.data_ptr() + 4 * lo, v=fv.data_ptr() + 4 * lo,
+                       hyper=hyper.data_ptr(), bf16_shadow=(shadow.data_ptr() + 2 * lo) if shadow is not None else None)
+        call("dvlp_wgrad_grouped_ex", d, n, ctypes.addressof(Ms), ctypes.addressof(Ns), ctypes.addressof(Ks), ctypes.addressof(A), ctypes.addressof(lda),
+             ctypes.addressof(Bp), ctypes.addressof(ldb), ctypes.addressof(C), 0, ctypes.byref(ext), stream())
+        return outs
     call("dvlp_wgrad_grouped", d, n, ctypes.addressof(Ms), ctypes.addressof(Ns), ctypes.addressof(Ks), ctypes.addressof(A), ctypes.addressof(lda),
          ctypes.addressof(Bp), ctypes.addressof(ldb), ctypes.addressof(C), 0, stream())
     return outs

@@ -180,14 +180,18 @@ class FusedAdamW:
         self._sync_hyper(grad_scale)
         ops.adamw_prep_dev(self._hyper)
         self._early = []
+        self._pending = {}
         Fn.EARLY_OPT = self._early_update
+        Fn.TAKE_PENDING_OPT = self._take_pending
 
     def abort_overlapped(self):
         """Drop an overlapped step that did not reach launch() (forward / backward raised): clears the per-layer hook and the record
         of early updates so the next zero_grad() / step starts clean.  Layers already updated stay updated (their moments too)."""
         if Fn.EARLY_OPT is not None and getattr(Fn.EARLY_OPT, "__self__", None) is self:
             Fn.EARLY_OPT = None
+            Fn.TAKE_PENDING_OPT = None
         self._early = None
+        self._pending = {}
         # begin_overlapped() already advanced the DEVICE step counter (adamw_prep_dev) while the host's step_count stays: make the next
         # _sync_hyper() rewrite the device counter from the host's, or every later step would run its bias correction one step ahead
         self._hyper_step = -1
@@ -202,14 +206,47 @@ class FusedAdamW:
                 runs[-1][1] = hi
             else:
                 runs.append([lo, hi])
-        for lo, hi in runs:
+        # Round 6: the layer's (contiguous) range is not launched here but left PENDING for the next grouped weight-gradient launch on this
+        # stream -- the layer below's, a few kernels later -- whose 40 spare workgroups (216 GEMM workgroups on 256 CUs) run it beside the
+        # products (dvlp_wgrad_grouped_ex) instead of as a 35-us launch of its own between two of them.  Per stream: the text tower's
+        # backward runs on its own stream when the towers are concurrent, and an update may only ride in a launch that is ordered behind
+        # the kernels that finished its gradients.
+        sid = torch.cuda.current_stream().cuda_stream
+        self._flush_pending(sid)                                 # (one nobody took: two layers without a weight-gradient group in between)
+        for lo, hi in runs[:-1]:
             ops.adamw_range_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s, lo, hi)
+        if runs:
+            self._pending[sid] = tuple(runs[-1])
+        for lo, hi in runs:
             self._early.append((lo, hi))
+
+    def _take_pending(self):
+        """(p, g, m, v, hyper, shadow, lo, hi) of the update pending on the CURRENT stream (then no longer pending), or None."""
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return None
+        r = pend.pop(torch.cuda.current_stream().cuda_stream, None)
+        if r is None:
+            return None
+        a = self.arena
+        return (a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s, r[0], r[1])
+
+    def _flush_pending(self, sid=None):
+        """Launch pending updates on their own (``sid``: only that stream's; None: all -- the caller has joined the streams)."""
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return
+        a = self.arena
+        for k in [k for k in pend if sid is None or k == sid]:
+            lo, hi = pend.pop(k)
+            ops.adamw_range_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s, lo, hi)
 
     def _finish_overlapped(self):
         """The ranges no layer updated, as few launches as the arena layout allows."""
         a = self.arena
         Fn.EARLY_OPT = None
+        Fn.TAKE_PENDING_OPT = None
+        self._flush_pending()
         done, self._early = sorted(self._early), None
         pos = 0
         for lo, hi in done + [(a.total, a.total)]:

@@ -51,6 +51,19 @@ int dvlp_gemm_batched(int dtype, int transA, int transB, int64_t M, int64_t N, i
    host arrays of length `count`.  bf16 problems that suit the 256 x 256 kernel run as one grouped launch. */
 int dvlp_wgrad_grouped(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
                        const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate, void* stream);
+/* The same with an optimizer update riding along (round 6): `ext` describes one dvlp_adamw_range_dev call -- the fused HF-AdamW pass over a
+   contiguous range of the flat parameter / gradient / moment buffers, typically the PREVIOUS layer's weights, whose gradients are final -- that
+   is executed by the workgroups this launch would leave idle (a ViT layer's group is 216 workgroups on 256 CUs) instead of as a launch of its
+   own between two GEMM launches; when the group has fewer than 16 spare workgroups (or does not take the grouped path) the update is launched
+   right behind it.  ext->fused (out) says which.  NULL ext = dvlp_wgrad_grouped. */
+typedef struct dvlp_wgrad_ext {
+    int64_t n;
+    float* p; const float* g; float* m; float* v; const float* hyper; void* bf16_shadow;
+    int fused;
+} dvlp_wgrad_ext;
+int dvlp_wgrad_grouped_ex(int dtype, int count, const int64_t* M, const int64_t* N, const int64_t* K, const void* const* dY,
+                          const int64_t* ld_dy, const void* const* X, const int64_t* ld_x, void* const* dW, int accumulate,
+                          dvlp_wgrad_ext* ext, void* stream);
 /* Per-stream hint, caller-registered like the workspaces: co_running != 0 says that launches on `stream` share the chip with kernels of another
    stream (the text tower beside the object tower, model.ObjectRelation.parallel_towers); the bf16 GEMM dispatch then favours CU-time per FLOP
    (tall tiles) over the latency of its own grid.  0 removes the hint. */

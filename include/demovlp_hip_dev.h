@@ -41,6 +41,9 @@ int dvlp_dev_wgrad_group_patches(int on);
 /* batched skinny products (N, K <= 288, M in the thousands: the local loss' per-video / per-caption contractions) on the resident-B streaming
    kernel (csrc/gemm_rb.hip): 1 (default) where its shapes fit, 0 never -- for A/B measurements and tests */
 int dvlp_dev_gemm_resident_b(int on);
+/* dvlp_wgrad_grouped_ex: 1 (default) the optimizer update it is handed rides on the launch's spare workgroups, 0 it is launched on its own --
+   for A/B measurements */
+int dvlp_dev_wgrad_group_ride(int on);
 /* number of workgroups a split-K launch aims for (default 768 = 3 per CU) */
 int dvlp_dev_gemm_splitk_target(int64_t n);
 /* space-mode bf16 backward: 1 (default) one pass over q/k/v/dO with the CLS query folded into the frame tiles, 0 the

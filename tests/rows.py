@@ -78,6 +78,7 @@ ROWS = {
     "test_gemm_pingpong_race_screen": "A3 A5",
     "test_deferred_reductions_match_immediate": "A3 A14",
     "test_wgrad_grouped_matches_single": "A3 A5 A14",
+    "test_optimizer_update_riding_in_the_grouped_weight_gradient_launch": "A14 A3",
     "test_region_batcher_ragged_files_match_reference_pipeline": "f2 A1",
     "test_gemm_fused_column_sums": "A3 A5",
     "test_gemm_resident_b_batched_against_the_tile_kernel_and_fp32": "A10",

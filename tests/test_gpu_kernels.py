@@ -587,6 +587,37 @@ def test_wgrad_grouped_matches_single(dtype, T):
             assert rel(o, single) < 1e-5, (sel, i)          # same products, possibly a different K split
 
 
+@pytest.mark.parametrize("T,sel", [(18496, [0, 1, 2, 3]), (6400, [0, 1, 2, 3]), (1153, [2])])
+def test_optimizer_update_riding_in_the_grouped_weight_gradient_launch(T, sel):
+    """dvlp_wgrad_grouped_ex (round 6): a fused HF-AdamW range update handed to the grouped weight-gradient launch is executed by the
+    workgroups that launch leaves idle (a ViT layer: 216 of 256), or right behind it when there is no room (the third case: a single small
+    problem takes the ungrouped path).  Either way parameters, moments and the bf16 shadow must come out BIT-EQUAL to the stand-alone
+    dvlp_adamw_range_dev launch, and the weight gradients equal to the plain grouped launch's."""
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    probs = [(rnd(T, N, dtype=torch.bfloat16, seed=i), rnd(T, K, dtype=torch.bfloat16, seed=10 + i), None) for i, (N, K) in enumerate(shapes)]
+    probs = [probs[i] for i in sel]
+    n, lo, hi = 7_080_000, 4096, 4096 + 7_077_888                      # a layer's range inside a larger arena
+    g0 = torch.Generator(device=DEV).manual_seed(5)
+    base = dict(p=torch.randn(n, device=DEV, generator=g0) * 0.02, g=torch.randn(n, device=DEV, generator=g0) * 1e-3,
+                m=torch.randn(n, device=DEV, generator=g0) * 1e-4, v=torch.rand(n, device=DEV, generator=g0) * 1e-6)
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-6, 0.01, 0.5, 3.0, 0.0], device=DEV)
+    ops.adamw_prep_dev(hyper)                                           # step 4, step_size written
+
+    def fresh():
+        return {k: t.clone() for k, t in base.items()} | {"s": torch.zeros(n, device=DEV, dtype=torch.bfloat16)}
+    a, b = fresh(), fresh()
+    want = ops.wgrad_grouped(probs)
+    ops.adamw_range_dev(a["p"], a["g"], a["m"], a["v"], hyper, a["s"], lo, hi)
+    got = ops.wgrad_grouped(probs, ride=(b["p"], b["g"], b["m"], b["v"], hyper, b["s"], lo, hi))
+    torch.cuda.synchronize()
+    for w, o in zip(want, got):
+        assert torch.equal(w, o)
+    for k in ("p", "m", "v", "s"):
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(b[k][:lo], (base[k] if k != "s" else torch.zeros_like(b["s"]))[:lo]) and torch.equal(b[k][hi:], (base[k] if k != "s" else torch.zeros_like(b["s"]))[hi:])
+    assert not torch.equal(b["p"][lo:hi], base["p"][lo:hi])              # the update did happen
+
+
 def test_region_batcher_ragged_files_match_reference_pipeline(tmp_path):
     """.npz files with different region counts -> pinned staging -> device selection == the loader's numpy pipeline
     (oracle.region_select, itself pinned to the reference by tests/golden/g1), bit for bit."""

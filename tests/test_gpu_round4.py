@@ -190,6 +190,13 @@ def test_fp32_finetune_then_evaluate_vs_reference(tag, lr):
     assert g[tag + "_t2v"][0] != g11["t2v"][0] or g[tag + "_v2t"][0] != g11["v2t"][0]
 
 
+# measured on MI355X (printed by the test), bounds = 2x the observation: ten bf16 optimisation steps move the similarity matrix more than the
+# bf16 forward alone does (G11: 7.6e-3)
+BF16_G14_SIM_TOL = 9e-2          # observed 4.3e-2 of max |sim|
+BF16_G14_R_AT_K = 4.0            # percentage points (observed 1.6: 2 / 100 of 256 t2v / v2t ranks moved, by at most 1 / 14 places)
+BF16_G14_MEANR = 1.0             # observed 0.24
+
+
 def test_bf16_finetune_then_evaluate_stays_within_the_stated_bounds():
     """The same through the bf16 MFMA path (bf16 weight shadows, fp32 masters and moments) at the config's lr: loss curve within 2e-3 of the
     reference's, retrieval metrics within the bf16 bounds of G11 (4 points on R@K, MedR within 2, MeanR within 1)."""
@@ -200,15 +207,20 @@ def test_bf16_finetune_then_evaluate_stays_within_the_stated_bounds():
     sims = g["lr1e-5_o2t_sims"].astype(np.float64)
     d = np.abs(res["o2t_sims"] - sims).max() / np.abs(sims).max()
     print("\nG14 bf16: loss curve dev %.2e of the loss; o2t rel dev %.2e" % (dc, d))
-    assert dc < 4e-3 and d < BF16_G11_SIM_TOL, (dc, d)
+    bad = []
+    if not (dc < 2e-3 and d < BF16_G14_SIM_TOL):
+        bad.append(("curve / sims", dc, d))
     for name, axis in (("t2v", 1), ("v2t", 0)):
         m = res["nested_val_metrics"][name + "_metrics"]
         refm = dict(zip(KEYS, g["lr1e-5_" + name][:6]))
         want, got = _match_ranks(sims, axis), _match_ranks(res["o2t_sims"], axis)
         print("   %s bf16: %d ranks changed (max by %d); R@1/5/10/50 %s vs %s; MedR %s vs %s; MeanR %.2f vs %.2f"
               % (name, (want != got).sum(), np.abs(want - got).max(), [round(m[k], 2) for k in KEYS[:4]], np.round(g["lr1e-5_" + name][:4], 2), m["MedR"], refm["MedR"], m["MeanR"], refm["MeanR"]))
-        assert all(abs(m[k] - refm[k]) <= BF16_G11_R_AT_K for k in KEYS[:4]), (name, m, refm)
-        assert abs(m["MedR"] - refm["MedR"]) <= 2.0 and abs(m["MeanR"] - refm["MeanR"]) <= BF16_G11_MEANR
+        if not all(abs(m[k] - refm[k]) <= BF16_G14_R_AT_K for k in KEYS[:4]):
+            bad.append((name, "R@K", [round(m[k] - refm[k], 2) for k in KEYS[:4]]))
+        if not (abs(m["MedR"] - refm["MedR"]) <= 2.0 and abs(m["MeanR"] - refm["MeanR"]) <= BF16_G14_MEANR):
+            bad.append((name, "MedR / MeanR", m["MedR"] - refm["MedR"], m["MeanR"] - refm["MeanR"]))
+    assert not bad, bad
 
 
 # measured on MI355X (profiles/r4_bf16_fidelity.txt), bounds = 2-2.5x the observation:
