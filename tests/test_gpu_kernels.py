@@ -596,7 +596,7 @@ def test_optimizer_update_riding_in_the_grouped_weight_gradient_launch(T, sel):
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
     probs = [(rnd(T, N, dtype=torch.bfloat16, seed=i), rnd(T, K, dtype=torch.bfloat16, seed=10 + i), None) for i, (N, K) in enumerate(shapes)]
     probs = [probs[i] for i in sel]
-    n, lo, hi = 7_080_000, 4096, 4096 + 7_077_888                      # a layer's range inside a larger arena
+    n, lo, hi = 7_090_000, 4096, 4096 + 7_077_888                      # a layer's range inside a larger arena
     g0 = torch.Generator(device=DEV).manual_seed(5)
     base = dict(p=torch.randn(n, device=DEV, generator=g0) * 0.02, g=torch.randn(n, device=DEV, generator=g0) * 1e-3,
                 m=torch.randn(n, device=DEV, generator=g0) * 1e-4, v=torch.rand(n, device=DEV, generator=g0) * 1e-6)
