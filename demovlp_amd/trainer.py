@@ -196,9 +196,9 @@ class FusedAdamW:
         # _sync_hyper() rewrite the device counter from the host's, or every later step would run its bias correction one step ahead
         self._hyper_step = -1
 
-    def _early_update(self, params):
+    def _early_update(self, params, now=False):
         a = self.arena
-        idx = sorted(self._index_of[id(q)] for q in params)
+        idx = sorted(self._index_of[id(q)] for q in params if id(q) in self._index_of)
         runs = []
         for i in idx:                                           # adjacent slices (a layer's matrices are) merge into one launch
             lo, hi = a.offsets[i], a.offsets[i] + (a.params[i].numel() + a.ALIGN - 1) // a.ALIGN * a.ALIGN
@@ -213,9 +213,9 @@ class FusedAdamW:
         # the kernels that finished its gradients.
         sid = torch.cuda.current_stream().cuda_stream
         self._flush_pending(sid)                                 # (one nobody took: two layers without a weight-gradient group in between)
-        for lo, hi in runs[:-1]:
+        for lo, hi in (runs if now else runs[:-1]):
             ops.adamw_range_dev(a.flat_p, a.flat_g, self.m, self.v, self._hyper, a.flat_s, lo, hi)
-        if runs:
+        if runs and not now:
             self._pending[sid] = tuple(runs[-1])
         for lo, hi in runs:
             self._early.append((lo, hi))

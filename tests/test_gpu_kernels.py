@@ -152,7 +152,7 @@ def test_colsum(dtype):
     assert rel(got, t.float().reshape(B, F, R, 768).sum((0, 2))) < tol(dtype)
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["cls-folded-fwd-and-bwd", "bwd-one-pass", "bwd-three-launch"])
+@pytest.fixture(params=[1, 0], ids=["bwd-one-pass", "bwd-three-launch"])
 def attn_bwd_variant(request):
     """bf16 space attention: the CLS query folded into the frame waves in forward AND backward (the forward's statistics handed to the
     backward: what VitBlockFn runs), the one-pass backward with its own statistics launch, and the three-launch backward."""
@@ -176,8 +176,6 @@ def test_space_attention(dtype, B, F, R):
 @pytest.mark.parametrize("B,F,R", ATTN_SHAPES)
 def test_space_attention_other_backward_forms(dtype, B, F, R, attn_bwd_variant):
     """The one-pass backward with its own statistics launch and the three-launch backward (developer switch), same bar."""
-    if attn_bwd_variant == 2:
-        pytest.skip("the default form runs on the product library: test_space_attention")
     _space_attention_case(dtype, B, F, R, attn_bwd_variant)
 
 
