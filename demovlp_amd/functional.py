@@ -153,7 +153,6 @@ def _early_update(params, now=False):
 
 
 FUSE_TEXT_QKV = os.environ.get("DVLP_NO_FUSED_QKV") is None      # developer switch for A/B timing
-EARLY_EMBED_UPDATE = os.environ.get("DVLP_NO_EARLY_EMBED_UPDATE") is None   # developer switch for A/B timing
 FUSE_LN_COLSUM = os.environ.get("DVLP_NO_LN_COLSUM") is None     # developer switch for A/B timing
 FUSE_GEMM_COLSUM = os.environ.get("DVLP_NO_GEMM_COLSUM") is None  # developer switch for A/B timing
 FUSE_ATTN_COLSUM = os.environ.get("DVLP_NO_ATTN_COLSUM") is None  # developer switch for A/B timing
@@ -488,11 +487,9 @@ class TextEmbedFn(torch.autograd.Function):
         dpos = torch.zeros_like(pos)
         ops.colsum_grouped(de, B, 768, L * 768, B, 0, L, 768, out=dpos[:L])       # sum over the batch per position, written in place
         dpos = _into(pos, dpos)
-        if gv is not None and EARLY_EMBED_UPDATE:
-            # both embedding tables (23.8 M of the 153 M parameters, the head of the arena) are final here, ~2.4 ms into a backward whose
-            # object-tower half runs ~5 ms longer: updated now -- on the text tower's stream when the towers are concurrent -- the 0.7 GB
-            # pass runs beside the object tower's products instead of in the step's tail
-            _early_update((word, pos), now=True)
+        # (round 6, measured and not kept: updating the two embedding tables here -- 0.7 GB of optimizer traffic on the text tower's stream
+        #  beside the object tower's backward instead of in the step's tail -- left the replayed step where it was: 16.99 / 16.97 / 17.00
+        #  against 16.97 / 16.99 / 17.01 ms)
         return None, dword, dpos, dg, db, None, None
 
 

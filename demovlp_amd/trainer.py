@@ -197,6 +197,7 @@ class FusedAdamW:
         self._hyper_step = -1
 
     def _early_update(self, params, now=False):
+        """``now``: launch the update here instead of leaving it pending for the next weight-gradient group of this stream."""
         a = self.arena
         idx = sorted(self._index_of[id(q)] for q in params if id(q) in self._index_of)
         runs = []
