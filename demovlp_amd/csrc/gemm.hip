@@ -1975,7 +1975,14 @@ static int wgrad_grouped_impl(int dtype, int count, const int64_t* M, const int6
         int spare = ncu - blk % ncu;                 // CUs the last round of GEMM blocks leaves idle (one workgroup per CU: 136 KB of LDS each)
         if (spare == ncu) spare = 0;
         if (spare > 64) spare = 64;                  // (a co-running, unsplit text-tower group leaves more than the update can use)
-        if (spare >= 16) {
+        // ... and only when the update does not become the launch's long pole: a CU streams ~22 GB/s through the 30 B per parameter of the
+        // pass, the products take ~1.3 us per K tile (+ ~15 us): a ViT layer's group (145 K tiles: ~205 us) covers its 241-us update on 40
+        // CUs, a DistilBERT layer's 2-way split group (50 K tiles: ~80 us) does not -- it ran 146 us with the update inside against 103 + 35
+        // apart (profiles/r6_mid_gemm_shapes.txt).  On a co-running stream the launch's own length is not what counts: always ride.
+        int64_t kt = 0;
+        for (int p = 0; p < count; ++p) kt = std::max<int64_t>(kt, cdiv(Km[p] / H_BK, S[p]));
+        const double gemm_us = 15.0 + 1.3 * (double)kt, upd_us = spare > 0 ? (double)ext->n * 30.0 / ((double)spare * 22e3) : 1e30;
+        if (spare >= 16 && (upd_us <= 1.3 * gemm_us || stream_co_running(stream))) {
             g.opt_blk0 = blk; g.opt_nblk = spare; g.opt_n = ext->n;
             g.opt_p = ext->p; g.opt_g = ext->g; g.opt_m = ext->m; g.opt_v = ext->v; g.opt_hyper = ext->hyper; g.opt_shadow = (bf16*)ext->bf16_shadow;
             blk += spare;
