@@ -322,3 +322,40 @@ def test_eval_grid_and_retrieval_metrics_vs_reference_golden():
         got = fn(sims.T.copy())
         assert np.allclose([got[k] for k in keys], g[f"grid_{name}"], rtol=1e-9, atol=1e-9), name
 
+
+
+def test_model_built_the_reference_way_from_pretrained_files_runs_on_their_weights(tmp_path, monkeypatch):
+    """The constructor's DEFAULT path on the device (model/model.py:29-36): a `pretrained/` directory as the reference expects it -- a HuggingFace
+    DistilBERT directory (safetensors, `distilbert.`-prefixed keys, dropout 0 in its config) and a timm-shaped ViT checkpoint -- is read by
+    `ObjectRelation(...)` with no opt-out, and the forward on the device is the oracle's forward on exactly the tensors the constructor left in
+    the model: what was loaded is what runs."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    F, R, B = 8, 30, 3
+    fill = syn.fill_state_dict(F, R)
+    d = tmp_path / "pretrained" / "distilbert-base-uncased"
+    os.makedirs(d)
+    json.dump(dict(model_type="distilbert", vocab_size=30522, max_position_embeddings=512, dim=768, hidden_dim=3072, n_layers=6, n_heads=12,
+                   dropout=0.0, attention_dropout=0.0), open(d / "config.json", "w"))
+    save_file({"distilbert." + k[len("text_model."):]: torch.from_numpy(v).contiguous() for k, v in fill.items() if k.startswith("text_model.")},
+              str(d / "model.safetensors"))
+    torch.save({k: torch.from_numpy(v) for k, v in syn.vit_checkpoint().items()}, tmp_path / "pretrained" / "jx_vit_base_p16_224-80ecf9dd.pth")
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(11)
+    model = ObjectRelation({"model": "", "input_objects": False, "object_num": R, "num_frames": F, "time_module": ""},
+                           {"model": "pretrained/distilbert-base-uncased", "pretrained": True, "input": "text", "two_outputs": True})
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    assert np.array_equal(sd["text_model.transformer.layer.3.ffn.lin1.weight"], fill["text_model.transformer.layer.3.ffn.lin1.weight"])
+    assert np.array_equal(sd["object_model.blocks.7.attn.qkv.weight"], syn.fill_tensor("vit/blocks.7.attn.qkv.weight", (2304, 768)))
+    assert model.text_model.config.dropout == 0.0 and model.text_model.training
+    model.to(DEV)
+    obj, mask, ids, att = golden_batch(F, R, B)
+    data = {"text": {"input_ids": torch.from_numpy(ids).to(DEV), "attention_mask": torch.from_numpy(att).to(DEV)},
+            "object": torch.from_numpy(obj).to(DEV), "object_mask": torch.from_numpy(mask).to(DEV)}
+    out = model(data)
+    p = orc.params_from_numpy(sd)
+    with torch.no_grad():
+        ref = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask).float())
+    for k in ("global_text_embeddings", "local_text_embeddings", "global_object_embeddings", "local_object_embeddings"):
+        assert rel_err(out[k].detach().float().cpu().numpy(), ref[k].numpy()) < 1e-4, k
