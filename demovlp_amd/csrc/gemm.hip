@@ -1666,7 +1666,11 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         //  count -- take 1 % off the step; alone they measured slower, above.  DVLP_P8_MIN_TILES=192 DVLP_P8_ROUNDS=1 restores round 2's rule)
         static const int p8_min_tiles = getenv("DVLP_P8_MIN_TILES") ? atoi(getenv("DVLP_P8_MIN_TILES")) : 64;      // experiments (round 3: 192 -> 64, see below)
         static const bool p8_need_rounds = getenv("DVLP_P8_ROUNDS") ? atoi(getenv("DVLP_P8_ROUNDS")) != 0 : false;
-        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= p8_min_tiles && (rounds8 || !p8_need_rounds)) || (tiles8 >= 8 && tiles8 <= 64 && K >= 4096))));
+        // (round 6: batched long-K reductions whose output half-fills its tiles -- the local loss' dC^_i [288 x 256] and dQ^_j [104 x 256] products
+        //  over K = 6 656 / 18 432, batch 64 -- also run faster here with a 2- / 4-way K split than on the 128-row kernel: 181 -> 132, 162 -> 122,
+        //  197 -> 160 us (profiles/r6_loss_reductions_on_p8.txt); a [104 x 104] output does not: 108 -> 132)
+        const bool longk8 = batch >= 8 && K >= 4096 && N % 256 == 0 && 10 * M >= 4 * ntm8 * 256;
+        const bool p8 = dma && K % H_BK == 0 && g_p8_mode != 0 && (g_p8_mode == 2 || longk8 || (M >= 256 && N >= 256 && fills8 && ((tiles8 >= p8_min_tiles && (rounds8 || !p8_need_rounds)) || (tiles8 >= 8 && tiles8 <= 64 && K >= 4096))));
         // Under-filled grids with a long reduction (weight gradients: 36-144 output tiles, K = B*N tokens) are split along
         // K so that ~3 workgroups (128-row kernel) or 1 workgroup (256-row kernel) land on every CU; partials go through fp32
         // slabs (deterministic, no float atomics).
@@ -1690,7 +1694,7 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
             // (a co-running launch is not split: slabs and a reduction launch buy latency it does not need with CU-time the other stream does --
             //  DVLP_CORUN_SPLIT=1 restores the split for A/B runs)
             static const bool corun_split = getenv("DVLP_CORUN_SPLIT") && atoi(getenv("DVLP_CORUN_SPLIT")) != 0;
-            if (g_ws && tiles < (p8 ? 128 : 200) && K >= 1024 && !(co_run && !corun_split)) {
+            if (g_ws && tiles < (p8 ? 129 : 200) && K >= 1024 && !(co_run && !corun_split)) {
                 S = p8 ? 256 / tiles : (g_splitk_target + tiles - 1) / tiles;
                 if (S > K / 256) S = K / 256;
                 if (S > 32) S = 32;
@@ -1742,6 +1746,10 @@ static int gemm_batched_impl(int dtype, int transA, int transB, int64_t M, int64
         const bool whole8 = N % 256 == 0 && (S > 1 ? N % 4 == 0 : e.vec != 0);
         const int ek8 = (g_ablate || !whole8) ? P8_EK_ANY : (S > 1 || fmask8 == 0) ? ((res && S == 1) ? 1 : 0) : (fmask8 == EPI_GELU && !res) ? 2 : (fmask8 == EPI_GELU_BWD && !res) ? 3 : P8_EK_ANY;
         if (ek8 == P8_EK_ANY && S == 1) mih8 = 4;        // run-time-flag epilogues exist at 256 rows only
+        // a many-round product with a very short K (the local loss' S = C^ Q^^T: 1 872 tiles of 4 K tiles each) is all prologue and epilogue: the
+        // persistent form (224-row tiles only) hides them behind the neighbouring tiles' K loops -- 105 -> 91.5 us -- whatever the planner's height
+        if (plan8 && g_p8_short == 1 && g_p8_persist != 0 && S == 1 && (ek8 == 0 || ek8 == 2) && K / H_BK >= 4 && K / H_BK <= 8 && (K / H_BK) % 2 == 0 &&
+            cdiv(M, 224) * ntn8 > 2 * ncu8) mih8 = 3;
         const int64_t rows8 = 128 + 32 * mih8;
         const int64_t ntm8h = cdiv(M, rows8);
         if (csum_dst && p8 && batch == 1 && S == 1 && e.vec && N % 256 == 0 && !(flags & EPI_OUT_F32)) {
