@@ -1771,7 +1771,7 @@ extern "C" int dvlp_attention_fwd_ex(int dtype, int mode, int64_t B, int64_t N, 
                 a.cls_o = workspace; a.cls_st = workspace + B * H * F * HD; a.cls_stats = cls_stats;
             }
             const bool small = (int64_t)B * N * (ld > ldo ? ld : ldo) * 2 < (int64_t)0x7fffff00;       // 32-bit byte offsets inside a tensor
-            if (g_attn_lean && a.cls_o && small && !(a.abl & 7)) {          // (the fold guarantees nqt == nkt <= 3)
+            if (g_attn_lean && a.cls_o && small) {          // (the fold guarantees nqt == nkt <= 3; of the ablation bits this kernel knows only 8)
                 const size_t l_ = (size_t)(SATTN_WAVES * nkt * 16 * VLD + 16 * VLD) * sizeof(bf16) + (size_t)SATTN_WAVES * (HD + 2) * sizeof(float);
                 const unsigned chunks = (unsigned)cdiv(F, SATTN_WAVES);
 #define SFWD(NT_) hipLaunchKernelGGL((sattn_fwd_kernel<NT_>), dim3((unsigned)(B * H), chunks), dim3(64 * SATTN_WAVES), l_, st, a)
@@ -1838,7 +1838,8 @@ extern "C" int dvlp_attention_bwd_ex(int dtype, int mode, int64_t B, int64_t N, 
         static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void*)attn_bwd_seg_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         bool done = false;
         // one-pass form (CLS query rides along in the frame tiles): needs R + 1 query rows in <= 3 tiles
-        if (mode == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0 && R + 1 <= 48 && g_attn_merged) {
+        // (timing ablations 1 / 2 / 4 exist in the three-launch kernel only: a run that sets them must not silently time an unablated one-pass kernel)
+        if (mode == 0 && ld % 8 == 0 && ldo % 8 == 0 && ldd % 8 == 0 && R + 1 <= 48 && g_attn_merged && !(a.abl & 7)) {
             const int nt = (int)cdiv(R + 1, 16), items = (int)(B * H * F);
             float* stats = workspace + B * H * F * 2 * HD;
             if (fwd_out && cls_stats && g_attn_fold) {      // statistics from the folded forward: no statistics pass, dq_cls from per-frame partials

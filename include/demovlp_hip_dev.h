@@ -51,8 +51,9 @@ int dvlp_dev_gemm_splitk_target(int64_t n);
 int dvlp_dev_attention_bwd_variant(int merged);
 /* space-mode bf16 with the CLS query folded: 1 (default) the round-5 kernels, 0 the round 3-4 ones -- for A/B measurements and tests */
 int dvlp_dev_attention_lean(int on);
-/* TIMING-ONLY ablation of the MFMA attention kernels (backward, round 3-4 form: 1 no stores, 2 no exp, 4 stop after the softmax; forward,
-   round-5 form: 8 loads and stores only -- what the access shape alone costs); 0 in production */
+/* TIMING-ONLY ablation of the MFMA attention kernels: backward 1 no stores, 2 no exp, 4 stop after the softmax -- these exist in the three-launch
+   backward only, which a call with any of them set is routed to (the one-pass forms are then not taken); forward, round-5 form: 8 loads and stores
+   only -- what the access shape alone costs; 0 in production */
 int dvlp_dev_attention_ablate(int bits);
 /* bf16, D = 768: 1 (default) half a wave per row with 16-byte accesses, 0 the generic row-per-wave kernel -- for A/B measurements */
 int dvlp_dev_layernorm_wide(int on);

@@ -1,5 +1,9 @@
+#!/usr/bin/env python
+"""The local loss' long-K batched reductions (dC^_i, dQ^_j, dKq_j) and its all-pairs product S on the 256 x 256 ping-pong kernel with forced K
+splits / tile heights against the default dispatch -- the table behind the `longk8` rule and the persistent-form rule of csrc/gemm.hip
+(profiles/r6_loss_reductions_on_p8.txt).      python tools/loss_reduction_sweep.py"""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from demovlp_amd import _lib, ops
