@@ -14,6 +14,7 @@ ROWS = {
     # ---- tests/test_abi.py
     "test_library_exports_every_declared_symbol": "b",
     "test_product_library_exports_no_developer_switch": "b",
+    "test_integration_doc_names_every_entry_point_with_the_reference_interface_it_replaces": "b",
     "test_size_helpers_run_on_host": "b",
     "test_bad_arguments_are_reported_not_launched": "b",
     "test_no_reference_or_oracle_import_in_product": "b c",

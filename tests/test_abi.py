@@ -32,6 +32,18 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(lib.exported_symbols()) == set(names)
 
 
+def test_integration_doc_names_every_entry_point_with_the_reference_interface_it_replaces():
+    """INTEGRATION.md section 2 maps every entry point of the product library to the reference code (file:line) it stands in for -- the table a
+    maintainer binds against; a new entry point without a row fails here."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rows = [ln for ln in doc.splitlines() if ln.startswith("| `dvlp_")]
+    named = set(re.findall(r"`(dvlp_\w+)`", " ".join(r.split("|")[1] for r in rows)))
+    assert named == set(declared_symbols()), sorted(set(declared_symbols()) ^ named)
+    for r in rows:
+        what = r.split("|")[2]
+        assert re.search(r"\w+\.py:\d+", what) or "no reference counterpart" in what or "autograd" in what, r[:80]
+
+
 def test_product_library_exports_no_developer_switch(lib):
     """`dvlp_dev_*` (A/B switches, timing ablations, forced code paths) exist only in the -DDVLP_DEV build: the shipped library has no
     process-global knob to flip (`nm -D libdemovlp_hip.so | grep dvlp_dev_` is empty), the developer build exports all of them on top of the
