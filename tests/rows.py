@@ -117,6 +117,7 @@ ROWS = {
     "test_text_tower_train_mode_dropout_vs_oracle": "A8",
     "test_graph_replay_draws_fresh_dropout_masks": "A8 A14",
     "test_parallel_towers_give_identical_results": "A7",
+    "test_soak_replayed_steps_hold_memory_and_learn": "A14 d",
     "test_qa_model_vs_reference_golden": "f4",
     "test_bench_launches_its_own_ranks": "e d",
     # ---- tests/test_gpu_round3.py
