@@ -85,6 +85,7 @@ ROWS = {
     "test_gemm_resident_b_batched_against_the_tile_kernel_and_fp32": "A10",
     "test_region_select_edge_counts": "A1",
     # ---- tests/test_gpu_model.py
+    "test_graft_entry_smoke_runs_and_checks_against_the_oracle": "b d",
     "test_fp32_forward_backward_vs_reference_golden": "A2 A3 A4 A5 A6 A7 A8 A9 A10 A11",
     "test_model_built_the_reference_way_from_pretrained_files_runs_on_their_weights": "b A7 A8",
     "test_fp32_gradients_vs_float64_oracle": "A2 A3 A4 A5 A6 A7 A8 A9 A10 A11 A14",

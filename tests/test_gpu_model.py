@@ -359,3 +359,12 @@ def test_model_built_the_reference_way_from_pretrained_files_runs_on_their_weigh
         ref = orc.model_forward(p, torch.from_numpy(ids), torch.from_numpy(att), torch.from_numpy(obj), torch.from_numpy(mask).float())
     for k in ("global_text_embeddings", "local_text_embeddings", "global_object_embeddings", "local_object_embeddings"):
         assert rel_err(out[k].detach().float().cpu().numpy(), ref[k].numpy()) < 1e-4, k
+
+
+def test_graft_entry_smoke_runs_and_checks_against_the_oracle(capsys):
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench: one small forward + backward through the C ABI, checked
+    against the oracle inside smoke() itself (it raises on a mismatch)."""
+    import __graft_entry__
+    __graft_entry__.smoke()
+    out = capsys.readouterr().out
+    assert "smoke: loss hip=" in out and "grad rel err" in out, out
