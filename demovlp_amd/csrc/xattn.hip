@@ -1095,10 +1095,56 @@ __global__ __launch_bounds__(256) void xcos_fwd_kernel(CosArgs a) {
             }
         }
     };
+    // bf16 (round 6): a row is 512 bytes -- 16 lanes x 32 bytes -- so a wave takes FOUR rows at a time and its three reductions stay inside
+    // 16-lane groups (4 DPP steps instead of a 64-lane butterfly per row and quantity): the sweep was issue-bound on the reductions at half
+    // of its HBM rate (84 us for the 218 MB of wc at B = 64)
+    auto sweep16 = [&](const bf16* raw0, const bf16* ctx0, float* st, int n, float& acc) {
+        constexpr int UB16 = 2;
+        const int sub = lane & 15, rq = wid * 4 + (lane >> 4);
+        float part = 0.f;
+        for (int b = 0; b < n; b += 16 * UB16) {
+            float x[UB16][16], y[UB16][16];
+#pragma unroll
+            for (int u = 0; u < UB16; ++u) {
+                const int r = b + 16 * u + rq < n ? b + 16 * u + rq : n - 1;
+                const bf16* xr = raw0 + (int64_t)r * XD + sub * 16; const bf16* yr = ctx0 + (int64_t)r * XD + sub * 16;
+                float t8[8];
+                ld8<bf16>(xr, t8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x[u][t] = t8[t];
+                ld8<bf16>(xr + 8, t8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x[u][8 + t] = t8[t];
+                ld8<bf16>(yr, t8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) y[u][t] = t8[t];
+                ld8<bf16>(yr + 8, t8);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) y[u][8 + t] = t8[t];
+            }
+#pragma unroll
+            for (int u = 0; u < UB16; ++u) {
+                const int r = b + 16 * u + rq;
+                float d = 0.f, nx = 0.f, ny = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { d += x[u][t] * y[u][t]; nx += x[u][t] * x[u][t]; ny += y[u][t] * y[u][t]; }
+                d = row16_sum(d); nx = sqrtf(row16_sum(nx)); ny = sqrtf(row16_sum(ny));
+                if (r < n && sub == 0) {
+                    part += d / fmaxf(nx * ny, 1e-8f);                      // cosine_similarity (loss.py:286-291)
+                    st[(int64_t)r * 2] = d; st[(int64_t)r * 2 + 1] = ny;
+                }
+            }
+        }
+        acc = wave_sum(part);
+    };
     {
         const int64_t r1 = ((int64_t)i * a.Bj + j) * a.Wp, r2 = ((int64_t)j * a.Bi + i) * a.G;
-        sweep((const T*)a.Qraw + (int64_t)j * a.W * XD, (const T*)a.wc + r1 * XD, a.st1 + r1 * 2, a.W, acc1);
-        if (!a.nc) sweep((const T*)a.Craw + (int64_t)i * a.G * XD, (const T*)a.wc2 + r2 * XD, a.st2 + r2 * 2, a.G, acc2);
+        if constexpr (sizeof(T) == 2) sweep16((const bf16*)a.Qraw + (int64_t)j * a.W * XD, (const bf16*)a.wc + r1 * XD, a.st1 + r1 * 2, a.W, acc1);
+        else sweep((const T*)a.Qraw + (int64_t)j * a.W * XD, (const T*)a.wc + r1 * XD, a.st1 + r1 * 2, a.W, acc1);
+        if (!a.nc) {
+            if constexpr (sizeof(T) == 2) sweep16((const bf16*)a.Craw + (int64_t)i * a.G * XD, (const bf16*)a.wc2 + r2 * XD, a.st2 + r2 * 2, a.G, acc2);
+            else sweep((const T*)a.Craw + (int64_t)i * a.G * XD, (const T*)a.wc2 + r2 * XD, a.st2 + r2 * 2, a.G, acc2);
+        }
         else {                                          // Gram form: (u, |wc2|) are there already
             float part = 0.f;
             for (int g = threadIdx.x; g < a.G; g += 256) part += a.st2[(r2 + g) * 2] / fmaxf(a.nc[(int64_t)i * a.G + g] * a.st2[(r2 + g) * 2 + 1], 1e-8f);
